@@ -1,0 +1,481 @@
+// elementwise.hip -- the element-wise / row / loss / optimiser kernels of one epoch.
+//
+// One entry point per live launcher of the reference's device TU
+// (src/cuda_utils.cu:229-390, kernels :12-227).  The reference launches
+// min(ceil(size/1024),1280) x 1024 threads and walks rows with ONE THREAD PER ROW
+// (serial, uncoalesced loop over the m columns: max_rows, max_row_indices, ...).
+// Here: streaming kernels move 16 B per lane (float4) when the buffer allows it,
+// row kernels give each row to a group of lanes inside a wave64 and reduce with
+// DPP/LDS-crossbar shuffles, grids are sized for 256 CUs.  All of these are HBM
+// passes over [n x m] fp32; none is reshaped into a GEMM.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu(float x, float slope) {
+    const float y = slope * x;
+    return x > y ? x : y;
+}
+
+// ---- streaming helpers ----------------------------------------------------
+template <typename F>
+__global__ __launch_bounds__(256) void map1_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                   size_t size, F f) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride) out[i] = f(in[i]);
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void map1_vec4_kernel(const float4 *__restrict__ in,
+                                                        float4 *__restrict__ out, size_t size4, F f) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size4; i += stride) {
+        float4 x = in[i];
+        x.x = f(x.x); x.y = f(x.y); x.z = f(x.z); x.w = f(x.w);
+        out[i] = x;
+    }
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void map2_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                   float *__restrict__ out, size_t size, F f) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride)
+        out[i] = f(a[i], b[i]);
+}
+
+template <typename F>
+__global__ __launch_bounds__(256) void map2_vec4_kernel(const float4 *__restrict__ a,
+                                                        const float4 *__restrict__ b,
+                                                        float4 *__restrict__ out, size_t size4, F f) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size4; i += stride) {
+        const float4 x = a[i], y = b[i];
+        float4 o;
+        o.x = f(x.x, y.x); o.y = f(x.y, y.y); o.z = f(x.z, y.z); o.w = f(x.w, y.w);
+        out[i] = o;
+    }
+}
+
+template <typename F>
+void launch_map1(hipStream_t st, const float *in, float *out, size_t size, F f) {
+    if (!size) return;
+    if (size % 4 == 0 && aligned16(in) && aligned16(out)) {
+        hipLaunchKernelGGL(map1_vec4_kernel<F>, dim3(stream_grid(size / 4)), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(in), reinterpret_cast<float4 *>(out), size / 4, f);
+    } else {
+        hipLaunchKernelGGL(map1_kernel<F>, dim3(stream_grid(size)), dim3(256), 0, st, in, out, size, f);
+    }
+    MGGCN_CHECK_LAUNCH();
+}
+
+template <typename F>
+void launch_map2(hipStream_t st, const float *a, const float *b, float *out, size_t size, F f) {
+    if (!size) return;
+    if (size % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(out)) {
+        hipLaunchKernelGGL(map2_vec4_kernel<F>, dim3(stream_grid(size / 4)), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(a), reinterpret_cast<const float4 *>(b),
+                           reinterpret_cast<float4 *>(out), size / 4, f);
+    } else {
+        hipLaunchKernelGGL(map2_kernel<F>, dim3(stream_grid(size)), dim3(256), 0, st, a, b, out, size, f);
+    }
+    MGGCN_CHECK_LAUNCH();
+}
+
+struct LreluFwd { float s; __device__ float operator()(float x) const { return lrelu(x, s); } };
+struct LreluBwd { float s; __device__ float operator()(float in, float g) const { return in > 0.f ? g : s * g; } };
+struct Axpby { float a, b; __device__ float operator()(float x, float y) const { return a * x + b * y; } };
+struct Aaxpby { float a, b; __device__ float operator()(float x, float y) const { return a * x * x + b * y; } };
+struct Axpy { float a; __device__ float operator()(float x, float y) const { return fmaf(a, x, y); } };
+struct Scal { float a; __device__ float operator()(float x) const { return x * a; } };
+
+// ---- row-indexed streaming kernels ----------------------------------------
+// mat[i] (= | +=) row[i % m]          reference src/cuda_utils.cu:40-51
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float *__restrict__ row,
+                                                             float *__restrict__ mat, size_t size,
+                                                             size_t m, int discard) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride) {
+        const float r = row[i % m];
+        mat[i] = discard ? r : mat[i] + r;
+    }
+}
+
+// mat[i] /= scalar[i / m]             reference src/cuda_utils.cu:75-79
+__global__ __launch_bounds__(256) void scale_rows_kernel(float *__restrict__ mat,
+                                                         const float *__restrict__ scalar, size_t size,
+                                                         size_t m) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride)
+        mat[i] /= scalar[i / m];
+}
+
+// out[i] = exp(mat[i] - scalar[i / m]) reference src/cuda_utils.cu:192-200
+__global__ __launch_bounds__(256) void subtract_rows_exp_kernel(const float *__restrict__ mat,
+                                                                const float *__restrict__ scalar,
+                                                                float *__restrict__ out, size_t size,
+                                                                size_t m) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride)
+        out[i] = expf(mat[i] - scalar[i / m]);
+}
+
+// ---- one wave64 per row ---------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// row max                              reference src/cuda_utils.cu:95-104
+__global__ __launch_bounds__(256) void max_rows_kernel(const float *__restrict__ mat,
+                                                       float *__restrict__ maxs, size_t n_rows, size_t m) {
+    const int lane = threadIdx.x & 63;
+    const size_t wstride = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n_rows; r += wstride) {
+        float mx = -INFINITY;
+        for (size_t c = lane; c < m; c += 64) mx = fmaxf(mx, mat[r * m + c]);
+        mx = wave_max(mx);
+        if (lane == 0) maxs[r] = mx;
+    }
+}
+
+// argmax, first maximum wins           reference src/cuda_utils.cu:119-133
+__device__ __forceinline__ void argmax_combine(float &v, uint32_t &i, float ov, uint32_t oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__global__ __launch_bounds__(256) void max_row_indices_kernel(const float *__restrict__ mat,
+                                                              int32_t *__restrict__ maxs, size_t n_rows,
+                                                              size_t m) {
+    const int lane = threadIdx.x & 63;
+    const size_t wstride = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n_rows; r += wstride) {
+        float mx = -INFINITY;
+        uint32_t idx = 0xFFFFFFFFu;
+        for (size_t c = lane; c < m; c += 64) {
+            const float x = mat[r * m + c];
+            if (x > mx) { mx = x; idx = (uint32_t)c; }   // strict >: earlier column of this lane wins
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const float ov = __shfl_xor(mx, off);
+            const uint32_t oi = __shfl_xor(idx, off);
+            argmax_combine(mx, idx, ov, oi);
+        }
+        // all -inf / NaN row: the reference's strict `max < x` never fires -> index 0
+        if (lane == 0) maxs[r] = idx == 0xFFFFFFFFu ? 0 : (int32_t)idx;
+    }
+}
+
+// values[r] = log(mat[r, indices[r]])  reference src/cuda_utils.cu:142-150
+__global__ __launch_bounds__(256) void index_log_rows_kernel(const float *__restrict__ mat,
+                                                             const int32_t *__restrict__ indices,
+                                                             float *__restrict__ values, size_t n_rows,
+                                                             size_t m) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride)
+        values[r] = logf(mat[r * m + (size_t)indices[r]]);
+}
+
+// mat[r, indices[r]] += alpha           reference src/cuda_utils.cu:159-164
+__global__ __launch_bounds__(256) void add_indexed_rows_kernel(float *__restrict__ mat,
+                                                               const int32_t *__restrict__ indices,
+                                                               float alpha, size_t n_rows, size_t m) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride)
+        mat[r * m + (size_t)indices[r]] += alpha;
+}
+
+// out[i] = (a[i] == b[i])               reference src/cuda_utils.cu:180-184
+__global__ __launch_bounds__(256) void is_equal_kernel(const int32_t *__restrict__ a,
+                                                       const int32_t *__restrict__ b,
+                                                       float *__restrict__ out, size_t size) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride)
+        out[i] = (float)(a[i] == b[i]);
+}
+
+// param -= step * m / (sqrt(v / c2) + eps)   reference src/cuda_utils.cu:208-218
+__global__ __launch_bounds__(256) void adam_final_kernel(float *__restrict__ param,
+                                                         const float *__restrict__ m,
+                                                         const float *__restrict__ v, float step, float c2,
+                                                         float eps, size_t size) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride)
+        param[i] -= step * m[i] / (sqrtf(v[i] / c2) + eps);
+}
+
+// ---- |x| sum: fixed-order two-level reduction (reproducible) ---------------
+constexpr unsigned kAsumBlocks = 1024;
+
+__global__ __launch_bounds__(256) void abssum_partial_kernel(const float *__restrict__ A, size_t size,
+                                                             float *__restrict__ partial) {
+    __shared__ float wsum[4];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride) s += fabsf(A[i]);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(256) void abssum_final_kernel(const float *__restrict__ partial, unsigned n,
+                                                           float *__restrict__ result) {
+    __shared__ float wsum[4];
+    float s = 0.f;
+    for (unsigned i = threadIdx.x; i < n; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *result = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// per-device scratch for the abssum partials, allocated on first use (never on a
+// captured launch path: the host layers call abssum once during warm-up)
+float *abssum_scratch() {
+    static float *scratch[64] = {nullptr};
+    int dev = 0;
+    MGGCN_CHECK_HIP(hipGetDevice(&dev));
+    MGGCN_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
+    if (!scratch[dev]) MGGCN_CHECK_HIP(hipMalloc(&scratch[dev], kAsumBlocks * sizeof(float)));
+    return scratch[dev];
+}
+
+// ---- fused softmax + cross-entropy + argmax + gradient ---------------------
+// One wave64 per row; the row's m <= 64*K logits live in K registers per lane.
+constexpr int kXentMaxPerLane = 16;  // m <= 1024
+
+template <int K>
+__global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restrict__ H,
+                                                                 const int32_t *__restrict__ Y,
+                                                                 size_t n_rows, size_t m, float grad_scale,
+                                                                 float *__restrict__ sums) {
+    __shared__ float s_loss[4], s_acc[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t wstride = ((size_t)gridDim.x * blockDim.x) >> 6;
+    float loss_acc = 0.f, corr_acc = 0.f;
+    for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n_rows; r += wstride) {
+        float x[K];
+        float mx = -INFINITY;
+        uint32_t idx = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const size_t c = (size_t)lane + 64u * k;
+            x[k] = c < m ? H[r * m + c] : -INFINITY;
+            if (x[k] > mx) { mx = x[k]; idx = (uint32_t)c; }
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const float ov = __shfl_xor(mx, off);
+            const uint32_t oi = __shfl_xor(idx, off);
+            argmax_combine(mx, idx, ov, oi);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const size_t c = (size_t)lane + 64u * k;
+            x[k] = c < m ? expf(x[k] - mx) : 0.f;
+            sum += x[k];
+        }
+        sum = wave_sum(sum);
+        const int32_t y = Y[r];
+        float py = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const size_t c = (size_t)lane + 64u * k;
+            if (c < m) {
+                const float o = x[k] / sum;
+                const bool hit = (int32_t)c == y;
+                if (hit) py = o;
+                H[r * m + c] = (hit ? o - 1.f : o) * grad_scale;
+            }
+        }
+        py = wave_sum(py);  // exactly one lane holds p_y
+        if (lane == 0) {
+            loss_acc += fabsf(logf(py));
+            // argmax of the softmax output == argmax of the logits (exp is monotone);
+            // a row whose maximum never beat -inf reports index 0 like the reference
+            corr_acc += ((idx == 0xFFFFFFFFu ? 0 : (int32_t)idx) == y) ? 1.f : 0.f;
+        }
+    }
+    if (lane == 0) { s_loss[wid] = loss_acc; s_acc[wid] = corr_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]));
+        atomicAdd(&sums[1], (s_acc[0] + s_acc[1]) + (s_acc[2] + s_acc[3]));
+    }
+}
+
+// ---- fused Adam -------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_fused_kernel(float *__restrict__ p, float *__restrict__ g,
+                                                         float *__restrict__ m, float *__restrict__ v,
+                                                         float step, float b1, float b2, float wd, float c2,
+                                                         float eps, size_t size) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < size; i += stride) {
+        const float pi = p[i];
+        const float gi = fmaf(wd, pi, g[i]);                 // axpy(W, G_W, wd)     gcn.hpp:163
+        const float mi = (1.f - b1) * gi + b1 * m[i];        // axpby                gcn.hpp:164
+        const float vi = (1.f - b2) * gi * gi + b2 * v[i];   // aaxpby               gcn.hpp:166
+        g[i] = gi; m[i] = mi; v[i] = vi;
+        p[i] = pi - step * mi / (sqrtf(vi / c2) + eps);      // adam_final           gcn.hpp:168
+    }
+}
+
+}  // namespace
+
+// ============================ C ABI =========================================
+MGGCN_API void mggcn_leaky_relu_forward_f32(mggcn_stream_t stream, const float *in, float *out,
+                                            size_t size, float alpha) {
+    launch_map1(as_stream(stream), in, out, size, LreluFwd{alpha});
+}
+
+MGGCN_API void mggcn_leaky_relu_backward_f32(mggcn_stream_t stream, const float *in, const float *G_in,
+                                             float *G_out, size_t size, float alpha) {
+    launch_map2(as_stream(stream), in, G_in, G_out, size, LreluBwd{alpha});
+}
+
+MGGCN_API void mggcn_broadcast_rows_f32(mggcn_stream_t stream, const float *row, float *mat, size_t size,
+                                        size_t m, int discard) {
+    if (!size) return;
+    MGGCN_REQUIRE(m > 0, "row width must be positive");
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3(stream_grid(size)), dim3(256), 0, as_stream(stream), row,
+                       mat, size, m, discard);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_scale_rows_f32(mggcn_stream_t stream, float *mat, const float *scalar, size_t size,
+                                    size_t m) {
+    if (!size) return;
+    MGGCN_REQUIRE(m > 0, "row width must be positive");
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(stream_grid(size)), dim3(256), 0, as_stream(stream), mat,
+                       scalar, size, m);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_max_rows_f32(mggcn_stream_t stream, const float *mat, float *maxs, size_t size,
+                                  size_t m) {
+    if (!size) return;
+    MGGCN_REQUIRE(m > 0 && size % m == 0, "size must be n_rows * m");
+    const size_t n_rows = size / m;
+    hipLaunchKernelGGL(max_rows_kernel, dim3(stream_grid(n_rows * 64)), dim3(256), 0, as_stream(stream), mat,
+                       maxs, n_rows, m);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_max_row_indices_f32(mggcn_stream_t stream, const float *mat, int32_t *maxs,
+                                         size_t size, size_t m) {
+    if (!size) return;
+    MGGCN_REQUIRE(m > 0 && size % m == 0, "size must be n_rows * m");
+    const size_t n_rows = size / m;
+    hipLaunchKernelGGL(max_row_indices_kernel, dim3(stream_grid(n_rows * 64)), dim3(256), 0,
+                       as_stream(stream), mat, maxs, n_rows, m);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_index_log_rows_f32(mggcn_stream_t stream, const float *mat, const int32_t *indices,
+                                        float *values, size_t size, size_t m) {
+    if (!size) return;
+    MGGCN_REQUIRE(m > 0 && size % m == 0, "size must be n_rows * m");
+    const size_t n_rows = size / m;
+    hipLaunchKernelGGL(index_log_rows_kernel, dim3(stream_grid(n_rows)), dim3(256), 0, as_stream(stream),
+                       mat, indices, values, n_rows, m);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_add_indexed_rows_f32(mggcn_stream_t stream, float *mat, const int32_t *indices,
+                                          float alpha, size_t size, size_t m) {
+    if (!size) return;
+    MGGCN_REQUIRE(m > 0 && size % m == 0, "size must be n_rows * m");
+    const size_t n_rows = size / m;
+    hipLaunchKernelGGL(add_indexed_rows_kernel, dim3(stream_grid(n_rows)), dim3(256), 0, as_stream(stream),
+                       mat, indices, alpha, n_rows, m);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_is_equal_i32(mggcn_stream_t stream, const int32_t *a, const int32_t *b, float *out,
+                                  size_t size) {
+    if (!size) return;
+    hipLaunchKernelGGL(is_equal_kernel, dim3(stream_grid(size)), dim3(256), 0, as_stream(stream), a, b, out,
+                       size);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_subtract_rows_exp_f32(mggcn_stream_t stream, const float *mat, const float *scalar,
+                                           float *out, size_t size, size_t m) {
+    if (!size) return;
+    MGGCN_REQUIRE(m > 0, "row width must be positive");
+    hipLaunchKernelGGL(subtract_rows_exp_kernel, dim3(stream_grid(size)), dim3(256), 0, as_stream(stream),
+                       mat, scalar, out, size, m);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_axpby_f32(mggcn_stream_t stream, const float *A, float *B, float alpha, float beta,
+                               size_t size) {
+    launch_map2(as_stream(stream), A, B, B, size, Axpby{alpha, beta});
+}
+
+MGGCN_API void mggcn_aaxpby_f32(mggcn_stream_t stream, const float *A, float *B, float alpha, float beta,
+                                size_t size) {
+    launch_map2(as_stream(stream), A, B, B, size, Aaxpby{alpha, beta});
+}
+
+MGGCN_API void mggcn_adam_final_f32(mggcn_stream_t stream, float *param, const float *m, const float *v,
+                                    float lr, float c1, float c2, float eps, size_t size) {
+    if (!size) return;
+    hipLaunchKernelGGL(adam_final_kernel, dim3(stream_grid(size)), dim3(256), 0, as_stream(stream), param, m,
+                       v, lr / c1, c2, eps, size);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_axpy_f32(mggcn_stream_t stream, const float *A, float *B, float alpha, size_t size) {
+    launch_map2(as_stream(stream), A, B, B, size, Axpy{alpha});
+}
+
+MGGCN_API void mggcn_scale_mat_f32(mggcn_stream_t stream, float *mat, float scalar, size_t size) {
+    launch_map1(as_stream(stream), mat, mat, size, Scal{scalar});
+}
+
+MGGCN_API void mggcn_abssum_f32(mggcn_stream_t stream, const float *A, size_t size, float *result_device) {
+    MGGCN_REQUIRE(result_device != nullptr, "null result pointer");
+    float *scratch = abssum_scratch();
+    const unsigned blocks = std::min<unsigned>(kAsumBlocks, stream_grid(size ? size : 1));
+    hipLaunchKernelGGL(abssum_partial_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), A, size, scratch);
+    MGGCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(abssum_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), scratch, blocks,
+                       result_device);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_softmax_xent_fused_f32(mggcn_stream_t stream, float *H, const int32_t *Y,
+                                            size_t n_rows, size_t m, float grad_scale, float *sums_device) {
+    if (!n_rows) return;
+    MGGCN_REQUIRE(m > 0 && m <= 64u * kXentMaxPerLane, "fused loss supports 1 <= m <= 1024 classes");
+    const dim3 grid(stream_grid(n_rows * 64)), block(256);
+    hipStream_t st = as_stream(stream);
+#define MGGCN_XENT(K)                                                                              \
+    hipLaunchKernelGGL(softmax_xent_fused_kernel<K>, grid, block, 0, st, H, Y, n_rows, m, grad_scale, \
+                       sums_device)
+    if (m <= 64) MGGCN_XENT(1);
+    else if (m <= 128) MGGCN_XENT(2);
+    else if (m <= 256) MGGCN_XENT(4);
+    else if (m <= 512) MGGCN_XENT(8);
+    else MGGCN_XENT(16);
+#undef MGGCN_XENT
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_adam_fused_f32(mggcn_stream_t stream, float *param, float *grad, float *m, float *v,
+                                    float lr, float beta1, float beta2, float weight_decay, float c1,
+                                    float c2, float eps, size_t size) {
+    if (!size) return;
+    hipLaunchKernelGGL(adam_fused_kernel, dim3(stream_grid(size)), dim3(256), 0, as_stream(stream), param,
+                       grad, m, v, lr / c1, beta1, beta2, weight_decay, c2, eps, size);
+    MGGCN_CHECK_LAUNCH();
+}

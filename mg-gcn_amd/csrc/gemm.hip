@@ -1,0 +1,292 @@
+// gemm.hip -- dense fp32 GEMM on the gfx950 matrix cores (the only MFMA path).
+//
+// Stands in for matmul(context, dn A, dn B, dn C, alpha, beta, A_T, B_T) =
+// cublasSgemm with swapped operands (reference src/cuda_utils.hpp:149-172):
+//     C = alpha * op(A) * op(B) + beta * C,   everything row-major.
+//
+// The shapes of a GCN epoch are tall and skinny:
+//   forward   H[n x in] . W[in x out]              n = 233 k, in <= 608, out <= 128
+//   backward  G_W = X^T[in x n] . G[n x out]       K = n  -> split over K
+//             G_out = G[n x out] . W^T[out x in]
+//             G_b = 1^T[1 x n] . G[n x out]
+// so the kernel is a 128 x {128|64} output tile per workgroup with the whole of N
+// in one or two tiles, K streamed in 32-deep steps through LDS, and a split-K
+// grid dimension for the tall reductions.  Arithmetic is
+// v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, bitwise a k-ordered fmaf chain
+// (no TF32-style truncation exists on gfx950), i.e. at least as accurate as the
+// reference's cublasSgemm.
+//
+// Tile anatomy (256 threads = 4 wave64):
+//   BN = 128: waves 2(M) x 2(N), each 64 x 64 = 2x2 MFMA blocks  (64 acc VGPRs)
+//   BN =  64: waves 4(M) x 1(N), each 32 x 64 = 1x2 MFMA blocks  (32 acc VGPRs)
+//   LDS: As[32][BM+pad] + Bs[32][BN+pad] fp32, k-major so the MFMA operand read
+//        (lane l -> row l&31, k l>>5) is a conflict-free ds_read_b32.
+//   Global->LDS goes through registers, prefetched one K-step ahead.
+//   Operands whose K index is the contiguous one (A not transposed, B transposed)
+//   are transposed on the LDS write; the others are copied with 16-byte stores.
+// Split-K partial tiles land in a caller-provided slab and are summed in split
+// order by a second kernel (reproducible; no float atomics).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+
+// Loads 4 consecutive elements along the contiguous dimension, zero-filled
+// outside [0, limit).  vec: the whole operand is 16-byte aligned with ld % 4 == 0.
+__device__ __forceinline__ float4 load4_guard(const float *__restrict__ p, long long first,
+                                              long long limit, bool vec) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (first + 3 < limit && vec) {
+        r = *reinterpret_cast<const float4 *>(p + first);
+    } else {
+        if (first + 0 < limit) r.x = p[first + 0];
+        if (first + 1 < limit) r.y = p[first + 1];
+        if (first + 2 < limit) r.z = p[first + 2];
+        if (first + 3 < limit) r.w = p[first + 3];
+    }
+    return r;
+}
+
+// One operand's tile staging.  R = rows of the tile in the M (or N) direction.
+// KCONTIG: the stored matrix is [R-dim][K] (K contiguous) -> transpose into Xs[k][r].
+// else   : the stored matrix is [K][R-dim] (R contiguous) -> straight copy.
+template <int R, bool KCONTIG>
+struct Stager {
+    static constexpr int PAD = KCONTIG ? 1 : 4;
+    static constexpr int LD = R + PAD;
+    static constexpr int SEGS = R * BK / 4 / 256;   // float4 segments per thread
+    float4 reg[SEGS];
+
+    __device__ __forceinline__ void load(const float *__restrict__ X, size_t ld, long long r0,
+                                         long long r_limit, long long k0, long long k_limit, bool vec,
+                                         int tid) {
+#pragma unroll
+        for (int s = 0; s < SEGS; s++) {
+            const int f = tid + 256 * s;
+            if (KCONTIG) {
+                const int r = f / (BK / 4), kq = f % (BK / 4);
+                const long long row = r0 + r;
+                reg[s] = row < r_limit ? load4_guard(X + (size_t)row * ld, k0 + kq * 4, k_limit, vec)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const int k = f / (R / 4), q = f % (R / 4);
+                const long long kk = k0 + k;
+                reg[s] = kk < k_limit ? load4_guard(X + (size_t)kk * ld, r0 + q * 4, r_limit, vec)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float *__restrict__ Xs, int tid) const {
+#pragma unroll
+        for (int s = 0; s < SEGS; s++) {
+            const int f = tid + 256 * s;
+            if (KCONTIG) {
+                const int r = f / (BK / 4), kq = f % (BK / 4);
+                Xs[(kq * 4 + 0) * LD + r] = reg[s].x;
+                Xs[(kq * 4 + 1) * LD + r] = reg[s].y;
+                Xs[(kq * 4 + 2) * LD + r] = reg[s].z;
+                Xs[(kq * 4 + 3) * LD + r] = reg[s].w;
+            } else {
+                const int k = f / (R / 4), q = f % (R / 4);
+                *reinterpret_cast<float4 *>(Xs + k * LD + q * 4) = reg[s];
+            }
+        }
+    }
+};
+
+template <bool A_KCONTIG, bool B_KCONTIG, int BN>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(
+    uint32_t M, uint32_t N, uint32_t K, float alpha, const float *__restrict__ A, size_t lda,
+    const float *__restrict__ B, size_t ldb, float beta, float *__restrict__ C, size_t ldc,
+    float *__restrict__ slab, uint32_t k_chunk, bool a_vec, bool b_vec) {
+    constexpr int WN = BN == 128 ? 2 : 1;           // waves along N
+    constexpr int WM = 4 / WN;                      // waves along M
+    constexpr int MI = BM / WM / 32;                // MFMA blocks per wave along M (2 or 1)
+    constexpr int NI = BN / WN / 32;                // along N (2)
+    using StA = Stager<BM, A_KCONTIG>;
+    using StB = Stager<BN, B_KCONTIG>;
+    __shared__ __attribute__((aligned(16))) float As[BK * StA::LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * StB::LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const long long m0 = (long long)blockIdx.x * BM, n0 = (long long)blockIdx.y * BN;
+    const long long k_begin = (long long)blockIdx.z * k_chunk;
+    const long long k_end = min((long long)K, k_begin + (long long)k_chunk);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    StA sa;
+    StB sb;
+    if (k_begin < k_end) {
+        sa.load(A, lda, m0, M, k_begin, k_end, a_vec, tid);
+        sb.load(B, ldb, n0, N, k_begin, k_end, b_vec, tid);
+    }
+    const int l31 = lane & 31, lhi = lane >> 5;
+    for (long long k0 = k_begin; k0 < k_end; k0 += BK) {
+        __syncthreads();                 // previous step's LDS reads are done
+        sa.store(As, tid);
+        sb.store(Bs, tid);
+        __syncthreads();
+        if (k0 + BK < k_end) {           // prefetch the next K-step under the MFMAs
+            sa.load(A, lda, m0, M, k0 + BK, k_end, a_vec, tid);
+            sb.load(B, ldb, n0, N, k0 + BK, k_end, b_vec, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; kk++) {
+            float a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+                a[i] = As[(kk * 2 + lhi) * StA::LD + wm * (BM / WM) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < NI; j++)
+                b[j] = Bs[(kk * 2 + lhi) * StB::LD + wn * (BN / WN) + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NI; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool to_slab = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const long long col = n0 + wn * (BN / WN) + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const long long row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row < M && col < N) {
+                    const float v = acc[i][j][r];
+                    if (to_slab) {
+                        slab[((size_t)blockIdx.z * M + row) * N + col] = v;
+                    } else {
+                        float *cp = C + (size_t)row * ldc + col;
+                        *cp = beta == 0.f ? alpha * v : fmaf(beta, *cp, alpha * v);
+                    }
+                }
+            }
+        }
+}
+
+// C = alpha * sum_z slab[z] + beta * C, z in increasing order
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float *__restrict__ slab,
+                                                                 uint32_t splits, uint32_t M, uint32_t N,
+                                                                 float alpha, float beta,
+                                                                 float *__restrict__ C, size_t ldc) {
+    const size_t total = (size_t)M * N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        float s = 0.f;
+        for (uint32_t z = 0; z < splits; z++) s += slab[(size_t)z * total + i];
+        float *cp = C + (i / N) * ldc + (i % N);
+        *cp = beta == 0.f ? alpha * s : fmaf(beta, *cp, alpha * s);
+    }
+}
+
+// C = beta * C (K == 0 degenerate case)
+__global__ __launch_bounds__(256) void gemm_scale_c_kernel(uint32_t M, uint32_t N, float beta,
+                                                           float *__restrict__ C, size_t ldc) {
+    const size_t total = (size_t)M * N;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        float *cp = C + (i / N) * ldc + (i % N);
+        *cp = beta == 0.f ? 0.f : beta * *cp;
+    }
+}
+
+struct Split {
+    uint32_t splits;
+    uint32_t k_chunk;   // multiple of BK
+};
+
+// Tall reductions: give every CU about two tiles' worth of K-slices.
+Split choose_split(uint32_t M, uint32_t N, uint32_t K) {
+    const uint32_t bn = N > 64 ? 128 : 64;
+    const uint64_t tiles = (uint64_t)((M + BM - 1) / BM) * ((N + bn - 1) / bn);
+    const uint32_t k_steps = (K + BK - 1) / BK;
+    uint32_t splits = 1;
+    if (tiles < (uint64_t)kNumCU && k_steps >= 16) {
+        const uint32_t want = (uint32_t)((2ull * kNumCU + tiles - 1) / tiles);
+        splits = std::min<uint32_t>(want, k_steps / 8);   // at least 8 K-steps per slice
+        splits = std::max<uint32_t>(splits, 1u);
+    }
+    const uint32_t steps_per = (k_steps + splits - 1) / splits;
+    splits = (k_steps + steps_per - 1) / steps_per;
+    return {splits ? splits : 1u, steps_per * BK};
+}
+
+}  // namespace
+
+MGGCN_API size_t mggcn_gemm_workspace_bytes(int trans_a, int trans_b, uint32_t M, uint32_t N, uint32_t K) {
+    (void)trans_a; (void)trans_b;
+    if (!M || !N || !K) return 0;
+    const Split s = choose_split(M, N, K);
+    return s.splits > 1 ? (size_t)s.splits * M * N * sizeof(float) : 0;
+}
+
+MGGCN_API void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
+                              uint32_t K, float alpha, const float *A, size_t lda, const float *B,
+                              size_t ldb, float beta, float *C, size_t ldc, void *workspace,
+                              size_t workspace_bytes) {
+    if (!M || !N) return;
+    hipStream_t st = as_stream(stream);
+    MGGCN_REQUIRE(C != nullptr && ldc >= N, "bad C / ldc");
+    if (!K) {
+        hipLaunchKernelGGL(gemm_scale_c_kernel, dim3(stream_grid((size_t)M * N)), dim3(256), 0, st, M, N, beta,
+                           C, ldc);
+        MGGCN_CHECK_LAUNCH();
+        return;
+    }
+    MGGCN_REQUIRE(A != nullptr && B != nullptr, "null operand");
+    MGGCN_REQUIRE(lda >= (trans_a ? M : K), "lda smaller than the stored row of A");
+    MGGCN_REQUIRE(ldb >= (trans_b ? K : N), "ldb smaller than the stored row of B");
+    const Split sp = choose_split(M, N, K);
+    float *slab = nullptr;
+    if (sp.splits > 1) {
+        MGGCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)sp.splits * M * N * sizeof(float),
+                      "split-K GEMM needs the workspace reported by mggcn_gemm_workspace_bytes");
+        slab = static_cast<float *>(workspace);
+    }
+    const bool a_vec = aligned16(A) && lda % 4 == 0;
+    const bool b_vec = aligned16(B) && ldb % 4 == 0;
+    const bool a_kc = !trans_a, b_kc = trans_b != 0;
+    const int bn = N > 64 ? 128 : 64;
+    const dim3 grid((M + BM - 1) / BM, (N + bn - 1) / bn, sp.splits), block(256);
+
+#define MGGCN_GEMM_LAUNCH(AK, BKC, BNV)                                                               \
+    hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKC, BNV>), grid, block, 0, st, M, N, K, alpha, A, lda, B, ldb, \
+                       beta, C, ldc, slab, sp.k_chunk, a_vec, b_vec)
+    if (bn == 128) {
+        if (a_kc && b_kc) MGGCN_GEMM_LAUNCH(true, true, 128);
+        else if (a_kc) MGGCN_GEMM_LAUNCH(true, false, 128);
+        else if (b_kc) MGGCN_GEMM_LAUNCH(false, true, 128);
+        else MGGCN_GEMM_LAUNCH(false, false, 128);
+    } else {
+        if (a_kc && b_kc) MGGCN_GEMM_LAUNCH(true, true, 64);
+        else if (a_kc) MGGCN_GEMM_LAUNCH(true, false, 64);
+        else if (b_kc) MGGCN_GEMM_LAUNCH(false, true, 64);
+        else MGGCN_GEMM_LAUNCH(false, false, 64);
+    }
+#undef MGGCN_GEMM_LAUNCH
+    MGGCN_CHECK_LAUNCH();
+    if (sp.splits > 1) {
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(stream_grid((size_t)M * N)), dim3(256), 0, st, slab,
+                           sp.splits, M, N, alpha, beta, C, ldc);
+        MGGCN_CHECK_LAUNCH();
+    }
+}

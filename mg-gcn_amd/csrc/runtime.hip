@@ -1,0 +1,108 @@
+// runtime.hip -- device / stream / event / memory entry points of the C ABI.
+// Stands in for the reference's per-GPU `context` (src/matrix.hpp:69-158) and the
+// cuda_malloc helpers (src/mg_gcn.hpp:74-90).  Thin on purpose: the host layers
+// (C++ headers, Python mirror) own all policy.
+#include "common.h"
+
+MGGCN_API int mggcn_abi_version(void) { return MGGCN_ABI_VERSION; }
+
+MGGCN_API int mggcn_device_count(void) {
+    int n = 0;
+    hipError_t st = hipGetDeviceCount(&n);
+    if (st != hipSuccess) {  // no driver / no GPU: report zero devices, do not abort
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+MGGCN_API void mggcn_set_device(int device) { MGGCN_CHECK_HIP(hipSetDevice(device)); }
+
+MGGCN_API int mggcn_get_device(void) {
+    int d = 0;
+    MGGCN_CHECK_HIP(hipGetDevice(&d));
+    return d;
+}
+
+MGGCN_API void mggcn_device_synchronize(void) { MGGCN_CHECK_HIP(hipDeviceSynchronize()); }
+
+MGGCN_API mggcn_stream_t mggcn_stream_create(int high_priority) {
+    int least = 0, greatest = 0;  // numerically: greatest priority is the smaller number
+    MGGCN_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s = nullptr;
+    MGGCN_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? greatest : least));
+    return s;
+}
+
+MGGCN_API void mggcn_stream_destroy(mggcn_stream_t stream) {
+    if (stream) MGGCN_CHECK_HIP(hipStreamDestroy(as_stream(stream)));
+}
+
+MGGCN_API void mggcn_stream_synchronize(mggcn_stream_t stream) {
+    MGGCN_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+}
+
+MGGCN_API mggcn_event_t mggcn_event_create(void) {
+    hipEvent_t e = nullptr;
+    MGGCN_CHECK_HIP(hipEventCreate(&e));
+    return e;
+}
+
+MGGCN_API void mggcn_event_destroy(mggcn_event_t event) {
+    if (event) MGGCN_CHECK_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+}
+
+MGGCN_API void mggcn_event_record(mggcn_event_t event, mggcn_stream_t stream) {
+    MGGCN_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(stream)));
+}
+
+MGGCN_API void mggcn_stream_wait_event(mggcn_stream_t stream, mggcn_event_t event) {
+    MGGCN_CHECK_HIP(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+}
+
+MGGCN_API void mggcn_event_synchronize(mggcn_event_t event) {
+    MGGCN_CHECK_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
+}
+
+MGGCN_API float mggcn_event_elapsed_ms(mggcn_event_t begin, mggcn_event_t end) {
+    float ms = 0.f;
+    MGGCN_CHECK_HIP(hipEventElapsedTime(&ms, reinterpret_cast<hipEvent_t>(begin),
+                                        reinterpret_cast<hipEvent_t>(end)));
+    return ms;
+}
+
+MGGCN_API void *mggcn_malloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes) MGGCN_CHECK_HIP(hipMalloc(&p, bytes));
+    return p;
+}
+
+MGGCN_API void mggcn_free(void *device_ptr) {
+    if (device_ptr) MGGCN_CHECK_HIP(hipFree(device_ptr));
+}
+
+MGGCN_API void *mggcn_malloc_host(size_t bytes) {
+    void *p = nullptr;
+    if (bytes) MGGCN_CHECK_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    return p;
+}
+
+MGGCN_API void mggcn_free_host(void *host_ptr) {
+    if (host_ptr) MGGCN_CHECK_HIP(hipHostFree(host_ptr));
+}
+
+MGGCN_API void mggcn_memcpy_h2d(void *dst, const void *src, size_t bytes, mggcn_stream_t stream) {
+    if (bytes) MGGCN_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+}
+
+MGGCN_API void mggcn_memcpy_d2h(void *dst, const void *src, size_t bytes, mggcn_stream_t stream) {
+    if (bytes) MGGCN_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+}
+
+MGGCN_API void mggcn_memcpy_d2d(void *dst, const void *src, size_t bytes, mggcn_stream_t stream) {
+    if (bytes) MGGCN_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+}
+
+MGGCN_API void mggcn_memset_zero(void *dst, size_t bytes, mggcn_stream_t stream) {
+    if (bytes) MGGCN_CHECK_HIP(hipMemsetAsync(dst, 0, bytes, as_stream(stream)));
+}

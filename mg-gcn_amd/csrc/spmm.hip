@@ -1,0 +1,385 @@
+// spmm.hip -- CSR SpMM  C = alpha*A*B + beta*C  for gfx950 (MI355X), fp32.
+//
+// Stands in for cusparseSpMM as the reference calls it (src/cuda_utils.hpp:15-32:
+// op N/N, CSR u32/u32/f32, row-major dense operands) and for its workspace query
+// (src/cuda_utils.hpp:94-102).  There is no reference kernel source: the
+// arithmetic lived inside cuSPARSE.  Written from the math.
+//
+// Shape of the work (Reddit): 233 k rows, 115 M non-zeros, mean
+// degree 493, maximum ~21 k, 128-wide fp32 feature rows (512 B).  Per SpMM the
+// non-zero stream is 0.92 GB and B is 119 MB -- B sits in the 256 MiB Infinity
+// Cache, so the kernel is a *row gather* at L2 / Infinity-Cache rate (59.8 GB of
+// 512-B row fetches), not an HBM stream.  Design consequences:
+//
+//  * one wave64 per work item (a row, or a <=kSplit-long slice of a heavy row);
+//    a 128-wide row is covered by 32 lanes x float4, so one wave-instruction
+//    (global_load_dwordx4, 1 KiB) fetches TWO neighbour rows, fully coalesced;
+//    8 such loads (16 rows, 8 KiB) are in flight per wave before the first FMA.
+//  * column indices / values are fetched 64 at a time with one coalesced load per
+//    wave and handed to the row loads through the LDS crossbar (ds_bpermute).
+//  * heavy-tailed degrees: at ~0.5 us per non-zero per wave a 21 k-row would run
+//    for ~10 ms on its own, longer than the rest of the kernel.  The plan cuts such
+//    rows into slices, sorts all items longest-first (LPT) and sums the slices'
+//    partial rows in a fixed order in a second, tiny kernel -> bitwise
+//    reproducible, no float atomics.
+//  * fp32 FMA accumulation in registers; alpha/beta/leaky-ReLU fused in the
+//    epilogue; beta == 0 never reads C.
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+
+struct SpmmItem {
+    uint32_t row;   // output row
+    uint32_t beg;   // first non-zero (absolute offset into indices/values)
+    uint32_t end;   // one past the last
+    uint32_t slot;  // kNoSlot: write C directly; else: partial-sum slot
+};
+
+struct SplitRow {
+    uint32_t row;
+    uint32_t first_slot;
+    uint32_t n_slots;
+    uint32_t pad;
+};
+
+__device__ __forceinline__ float lrelu(float x, float slope) {
+    const float y = slope * x;
+    return x > y ? x : y;  // max(x, slope*x), reference src/cuda_utils.cu:26-31
+}
+
+__device__ __forceinline__ float4 fma4(float s, float4 b, float4 a) {
+    a.x = fmaf(s, b.x, a.x);
+    a.y = fmaf(s, b.y, a.y);
+    a.z = fmaf(s, b.z, a.z);
+    a.w = fmaf(s, b.w, a.w);
+    return a;
+}
+
+// ---------------------------------------------------------------------------
+// Vector path: d % 4 == 0, 16-byte aligned rows.  LPR lanes cover one feature row
+// with float4 each (LPR*4 columns per pass); G = 64/LPR neighbour rows are
+// fetched by one wave-instruction.  Wider d loops over column tiles.
+// ---------------------------------------------------------------------------
+template <int LPR, int UNROLL, bool HAS_ITEMS>
+__global__ __launch_bounds__(256) void spmm_vec4_kernel(
+    const SpmmItem *__restrict__ items, uint32_t n_items, const uint32_t *__restrict__ indptr,
+    const uint32_t *__restrict__ indices, const float *__restrict__ values,
+    const float *__restrict__ B, size_t ldb, float *__restrict__ C, size_t ldc,
+    float *__restrict__ partial, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave =
+        __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wave >= n_items) return;
+
+    uint32_t row, beg, end, slot;
+    if (HAS_ITEMS) {
+        const SpmmItem it = items[wave];
+        row = it.row; beg = it.beg; end = it.end; slot = it.slot;
+    } else {
+        row = wave; beg = indptr[wave]; end = indptr[wave + 1]; slot = kNoSlot;
+    }
+    const int sub = lane % LPR;
+    const int grp = lane / LPR;
+
+    for (uint32_t col0 = 0; col0 < d; col0 += LPR * 4) {
+        const uint32_t col = col0 + sub * 4;
+        const bool active = col < d;
+        const float *__restrict__ Bc = B + col;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+        // software pipeline over 64-entry chunks of the row: the next chunk's
+        // (index, value) pair is in flight while the current chunk's rows are gathered
+        uint32_t nxt_c = 0;
+        float nxt_v = 0.f;
+        if (beg + lane < end) { nxt_c = indices[beg + lane]; nxt_v = values[beg + lane]; }
+        for (uint32_t base = beg; base < end; base += 64) {
+            const uint32_t my_c = nxt_c;
+            const float my_v = nxt_v;
+            const uint32_t e_next = base + 64 + lane;
+            nxt_c = 0; nxt_v = 0.f;
+            if (e_next < end) { nxt_c = indices[e_next]; nxt_v = values[e_next]; }
+            const uint32_t cnt = min(64u, end - base);
+            for (uint32_t j = 0; j < cnt; j += G * UNROLL) {
+                float4 b[UNROLL];
+                float v[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    const uint32_t src = j + u * G + grp;   // < 64 + G*UNROLL
+                    const uint32_t c = __shfl(my_c, src & 63);
+                    const float vv = __shfl(my_v, src & 63);
+                    const bool ok = active && src < cnt;
+                    v[u] = ok ? vv : 0.f;
+                    b[u] = ok ? *reinterpret_cast<const float4 *>(Bc + (size_t)c * ldb)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) acc = fma4(v[u], b[u], acc);
+            }
+        }
+        // fold the G lane groups (fixed order -> reproducible)
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off);
+            acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off);
+            acc.w += __shfl_xor(acc.w, off);
+        }
+        if (grp == 0 && active) {
+            if (slot == kNoSlot) {
+                float4 o = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+                float4 *cp = reinterpret_cast<float4 *>(C + (size_t)row * ldc + col);
+                if (beta != 0.f) {
+                    const float4 c0 = *cp;
+                    o.x = fmaf(beta, c0.x, o.x); o.y = fmaf(beta, c0.y, o.y);
+                    o.z = fmaf(beta, c0.z, o.z); o.w = fmaf(beta, c0.w, o.w);
+                }
+                if (flags & MGGCN_SPMM_LEAKY_RELU) {
+                    o.x = lrelu(o.x, slope); o.y = lrelu(o.y, slope);
+                    o.z = lrelu(o.z, slope); o.w = lrelu(o.w, slope);
+                }
+                *cp = o;
+            } else {
+                *reinterpret_cast<float4 *>(partial + (size_t)slot * d + col) = acc;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Scalar path: any d / any alignment (the reference's d = 41 logits layer has
+// 164-byte rows).  One lane per column, one neighbour row per wave-instruction;
+// index/value broadcast through v_readlane (wave-uniform -> scalar registers).
+// ---------------------------------------------------------------------------
+template <int UNROLL, bool HAS_ITEMS>
+__global__ __launch_bounds__(256) void spmm_scalar_kernel(
+    const SpmmItem *__restrict__ items, uint32_t n_items, const uint32_t *__restrict__ indptr,
+    const uint32_t *__restrict__ indices, const float *__restrict__ values,
+    const float *__restrict__ B, size_t ldb, float *__restrict__ C, size_t ldc,
+    float *__restrict__ partial, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave =
+        __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wave >= n_items) return;
+    uint32_t row, beg, end, slot;
+    if (HAS_ITEMS) {
+        const SpmmItem it = items[wave];
+        row = it.row; beg = it.beg; end = it.end; slot = it.slot;
+    } else {
+        row = wave; beg = indptr[wave]; end = indptr[wave + 1]; slot = kNoSlot;
+    }
+    for (uint32_t col0 = 0; col0 < d; col0 += 64) {
+        const uint32_t col = col0 + lane;
+        const bool active = col < d;
+        const float *__restrict__ Bc = B + (active ? col : 0);
+        float acc = 0.f;
+        uint32_t nxt_c = 0;
+        float nxt_v = 0.f;
+        if (beg + lane < end) { nxt_c = indices[beg + lane]; nxt_v = values[beg + lane]; }
+        for (uint32_t base = beg; base < end; base += 64) {
+            const uint32_t my_c = nxt_c;
+            const float my_v = nxt_v;
+            const uint32_t e_next = base + 64 + lane;
+            nxt_c = 0; nxt_v = 0.f;
+            if (e_next < end) { nxt_c = indices[e_next]; nxt_v = values[e_next]; }
+            const uint32_t cnt = min(64u, end - base);
+            for (uint32_t j = 0; j < cnt; j += UNROLL) {
+                float b[UNROLL], v[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    const uint32_t src = (j + u) & 63;     // wave-uniform
+                    const uint32_t c = __builtin_amdgcn_readlane(my_c, src);
+                    const float vv = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, my_v), src));
+                    const bool ok = (j + u) < cnt;            // padded lanes carry v = 0, c = 0
+                    v[u] = ok ? vv : 0.f;
+                    b[u] = (ok && active) ? Bc[(size_t)c * ldb] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) acc = fmaf(v[u], b[u], acc);
+            }
+        }
+        if (active) {
+            if (slot == kNoSlot) {
+                float o = alpha * acc;
+                float *cp = C + (size_t)row * ldc + col;
+                if (beta != 0.f) o = fmaf(beta, *cp, o);
+                if (flags & MGGCN_SPMM_LEAKY_RELU) o = lrelu(o, slope);
+                *cp = o;
+            } else {
+                partial[(size_t)slot * d + col] = acc;
+            }
+        }
+    }
+}
+
+// Sum the slices of every split row in slot order, then the common epilogue.
+__global__ __launch_bounds__(256) void spmm_combine_kernel(
+    const SplitRow *__restrict__ rows, uint32_t n_split, const float *__restrict__ partial,
+    float *__restrict__ C, size_t ldc, uint32_t d, float alpha, float beta, uint32_t flags,
+    float slope) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave =
+        __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wave >= n_split) return;
+    const SplitRow sr = rows[wave];
+    for (uint32_t col = lane; col < d; col += 64) {
+        float acc = 0.f;
+        for (uint32_t s = 0; s < sr.n_slots; s++) acc += partial[(size_t)(sr.first_slot + s) * d + col];
+        float o = alpha * acc;
+        float *cp = C + (size_t)sr.row * ldc + col;
+        if (beta != 0.f) o = fmaf(beta, *cp, o);
+        if (flags & MGGCN_SPMM_LEAKY_RELU) o = lrelu(o, slope);
+        *cp = o;
+    }
+}
+
+uint32_t env_u32(const char *name, uint32_t dflt) {
+    const char *s = std::getenv(name);
+    if (!s || !*s) return dflt;
+    return (uint32_t)std::strtoul(s, nullptr, 10);
+}
+
+}  // namespace
+
+struct mggcn_spmm_plan {
+    uint32_t n_rows = 0, n_cols = 0, max_d = 0;
+    uint32_t n_items = 0, n_split_rows = 0, n_slots = 0;
+    SpmmItem *d_items = nullptr;
+    SplitRow *d_split = nullptr;
+    float *d_partial = nullptr;
+    size_t bytes = 0;
+    int device = 0;
+};
+
+MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,
+                                                  const uint32_t *host_indptr, uint32_t max_d) {
+    MGGCN_REQUIRE(host_indptr != nullptr || n_rows == 0, "plan needs the host copy of indptr");
+    MGGCN_REQUIRE(max_d > 0, "max_d must be positive");
+    // slice length for heavy rows; rows up to 1.5x the slice stay whole
+    const uint32_t split = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_SPLIT", 512u));
+
+    std::vector<SpmmItem> items;
+    std::vector<SplitRow> split_rows;
+    items.reserve((size_t)n_rows + 1024);
+    uint32_t n_slots = 0;
+    for (uint32_t r = 0; r < n_rows; r++) {
+        const uint32_t b = host_indptr[r], e = host_indptr[r + 1];
+        MGGCN_REQUIRE(e >= b, "indptr must be non-decreasing");
+        const uint32_t len = e - b;
+        if (len <= split + split / 2) {
+            items.push_back({r, b, e, kNoSlot});
+        } else {
+            const uint32_t parts = (len + split - 1) / split;
+            split_rows.push_back({r, n_slots, parts, 0});
+            for (uint32_t k = 0; k < parts; k++) {
+                const uint32_t kb = b + (uint32_t)((uint64_t)len * k / parts);
+                const uint32_t ke = b + (uint32_t)((uint64_t)len * (k + 1) / parts);
+                items.push_back({r, kb, ke, n_slots++});
+            }
+        }
+    }
+    // longest first (LPT); ties keep row order so neighbouring waves touch neighbouring C rows
+    std::stable_sort(items.begin(), items.end(), [](const SpmmItem &a, const SpmmItem &b) {
+        return (a.end - a.beg) > (b.end - b.beg);
+    });
+
+    auto *plan = new mggcn_spmm_plan;
+    plan->n_rows = n_rows; plan->n_cols = n_cols; plan->max_d = max_d;
+    plan->n_items = (uint32_t)items.size();
+    plan->n_split_rows = (uint32_t)split_rows.size();
+    plan->n_slots = n_slots;
+    MGGCN_CHECK_HIP(hipGetDevice(&plan->device));
+    const size_t ib = items.size() * sizeof(SpmmItem), sb = split_rows.size() * sizeof(SplitRow);
+    const size_t pb = (size_t)n_slots * max_d * sizeof(float);
+    if (ib) {
+        MGGCN_CHECK_HIP(hipMalloc(&plan->d_items, ib));
+        MGGCN_CHECK_HIP(hipMemcpy(plan->d_items, items.data(), ib, hipMemcpyHostToDevice));
+    }
+    if (sb) {
+        MGGCN_CHECK_HIP(hipMalloc(&plan->d_split, sb));
+        MGGCN_CHECK_HIP(hipMemcpy(plan->d_split, split_rows.data(), sb, hipMemcpyHostToDevice));
+    }
+    if (pb) MGGCN_CHECK_HIP(hipMalloc(&plan->d_partial, pb));
+    plan->bytes = ib + sb + pb;
+    return plan;
+}
+
+MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {
+    if (!plan) return;
+    if (plan->d_items) MGGCN_CHECK_HIP(hipFree(plan->d_items));
+    if (plan->d_split) MGGCN_CHECK_HIP(hipFree(plan->d_split));
+    if (plan->d_partial) MGGCN_CHECK_HIP(hipFree(plan->d_partial));
+    delete plan;
+}
+
+MGGCN_API uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan) { return plan->n_items; }
+MGGCN_API uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan) { return plan->n_split_rows; }
+MGGCN_API size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan) { return plan->bytes; }
+
+namespace {
+
+template <bool HAS_ITEMS>
+void launch_main(hipStream_t st, const mggcn_spmm_plan *plan, uint32_t n_items, const uint32_t *indptr,
+                 const uint32_t *indices, const float *values, const float *B, size_t ldb, float *C,
+                 size_t ldc, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    const SpmmItem *items = HAS_ITEMS ? plan->d_items : nullptr;
+    float *partial = HAS_ITEMS ? plan->d_partial : nullptr;
+    const unsigned block = 256, waves_per_block = block / 64;
+    const unsigned grid = (n_items + waves_per_block - 1) / waves_per_block;
+    const bool vec_ok = (d % 4 == 0) && (ldb % 4 == 0) && (ldc % 4 == 0) && aligned16(B) && aligned16(C);
+    if (vec_ok && d > 64) {
+        hipLaunchKernelGGL((spmm_vec4_kernel<32, 8, HAS_ITEMS>), dim3(grid), dim3(block), 0, st, items,
+                           n_items, indptr, indices, values, B, ldb, C, ldc, partial, d, alpha, beta,
+                           flags, slope);
+    } else if (vec_ok && d > 32) {
+        hipLaunchKernelGGL((spmm_vec4_kernel<16, 4, HAS_ITEMS>), dim3(grid), dim3(block), 0, st, items,
+                           n_items, indptr, indices, values, B, ldb, C, ldc, partial, d, alpha, beta,
+                           flags, slope);
+    } else if (vec_ok) {
+        hipLaunchKernelGGL((spmm_vec4_kernel<8, 2, HAS_ITEMS>), dim3(grid), dim3(block), 0, st, items,
+                           n_items, indptr, indices, values, B, ldb, C, ldc, partial, d, alpha, beta,
+                           flags, slope);
+    } else {
+        hipLaunchKernelGGL((spmm_scalar_kernel<8, HAS_ITEMS>), dim3(grid), dim3(block), 0, st, items,
+                           n_items, indptr, indices, values, B, ldb, C, ldc, partial, d, alpha, beta,
+                           flags, slope);
+    }
+    MGGCN_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+MGGCN_API void mggcn_spmm_csr_f32(mggcn_stream_t stream, const mggcn_spmm_plan *plan, uint32_t n_rows,
+                                  uint32_t n_cols, const uint32_t *indptr, const uint32_t *indices,
+                                  const float *values, const float *B, size_t ldb, float *C,
+                                  size_t ldc, uint32_t d, float alpha, float beta, uint32_t flags,
+                                  float slope) {
+    if (n_rows == 0 || d == 0) return;
+    MGGCN_REQUIRE(indptr && B && C, "null operand");
+    MGGCN_REQUIRE(ldb >= d && ldc >= d, "leading dimension smaller than the feature width");
+    MGGCN_REQUIRE((const void *)B != (const void *)C, "C must not alias B");
+    MGGCN_REQUIRE((uint64_t)n_cols * ldb < (1ull << 40), "B too large");
+    hipStream_t st = as_stream(stream);
+    if (plan) {
+        MGGCN_REQUIRE(plan->n_rows == n_rows && plan->n_cols == n_cols, "plan built for another matrix");
+        MGGCN_REQUIRE(d <= plan->max_d || plan->n_slots == 0, "feature width exceeds the plan's max_d");
+        launch_main<true>(st, plan, plan->n_items, indptr, indices, values, B, ldb, C, ldc, d, alpha,
+                          beta, flags, slope);
+        if (plan->n_split_rows) {
+            const unsigned grid = (plan->n_split_rows + 3) / 4;
+            hipLaunchKernelGGL(spmm_combine_kernel, dim3(grid), dim3(256), 0, st, plan->d_split,
+                               plan->n_split_rows, plan->d_partial, C, ldc, d, alpha, beta, flags, slope);
+            MGGCN_CHECK_LAUNCH();
+        }
+    } else {
+        launch_main<false>(st, nullptr, n_rows, indptr, indices, values, B, ldb, C, ldc, d, alpha, beta,
+                           flags, slope);
+    }
+}

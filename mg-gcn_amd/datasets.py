@@ -1,0 +1,191 @@
+"""On-disk dataset format and synthetic graph generators (host side, numpy).
+
+The format is the one the reference's data-prep script writes and its binary
+reads (reference: test/data/prep.py:46-76 writer, :198-209 reader;
+src/matrix.hpp:224-234 and :486-492 readers; src/main.cpp:82-85 file names):
+
+``graph.bin``     ASCII ``PIGO-CSR-v2`` | u8 4 | u8 4 | u32 n | u32 nnz | u32 nrows |
+                  u32 ncols | u32 indptr[nrows+1] | u32 indices[nnz] | f32 data[nnz]
+``features.bin``  u32 N | u32 M | f32 payload, row-major
+``labels.bin``    u32 N | u32 1 | u32 payload (read back as int32)
+``sets.bin``      u32 N | u32 1 | u32 payload (0 train / 1 val / 2 test)
+
+Only 4-byte index / offset widths are supported, as in the reference
+(``x_t = v_t = unsigned``, src/main.cpp:43-45).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+MAGIC = b"PIGO-CSR-v2"
+
+
+class format_error(RuntimeError):
+    """Mirrors matrix_error (reference src/matrix.hpp:32-37): unsupported / malformed file."""
+
+
+def write_csr(path: str, indptr, indices, data, n_cols: Optional[int] = None) -> None:
+    indptr = np.ascontiguousarray(indptr, dtype="<u4")
+    indices = np.ascontiguousarray(indices, dtype="<u4")
+    data = np.ascontiguousarray(data, dtype="<f4")
+    n = indptr.shape[0] - 1
+    nnz = int(indptr[-1])
+    if n_cols is None:
+        n_cols = n
+    if indices.shape[0] != nnz or data.shape[0] != nnz:
+        raise format_error("indptr[-1] does not match indices/data length")
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        f.write(np.array([4, 4], dtype=np.uint8).tobytes())
+        f.write(np.array([n, nnz, n, n_cols], dtype="<u4").tobytes())
+        f.write(indptr.tobytes())
+        f.write(indices.tobytes())
+        f.write(data.tobytes())
+
+
+def read_csr(path: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray, int, int]:
+    """Returns (indptr u32[n+1], indices u32[nnz], data f32[nnz], n_rows, n_cols)."""
+    if not str(path).endswith(".bin"):
+        raise format_error("File type is not supported.")      # reference src/matrix.hpp:282
+    with open(path, "rb") as f:
+        head = f.read(13)
+        if len(head) != 13 or head[:11] != MAGIC:
+            raise format_error(f"{path}: not a PIGO-CSR-v2 file")
+        if head[11] != 4 or head[12] != 4:
+            raise format_error(f"{path}: only 4-byte index/offset widths are supported")
+        hdr = np.frombuffer(f.read(16), dtype="<u4")
+        if hdr.shape[0] != 4:
+            raise format_error(f"{path}: truncated header")
+        _n, nnz, nrows, ncols = (int(x) for x in hdr)
+        indptr = np.fromfile(f, dtype="<u4", count=nrows + 1)
+        indices = np.fromfile(f, dtype="<u4", count=nnz)
+        data = np.fromfile(f, dtype="<f4", count=nnz)
+    if indptr.shape[0] != nrows + 1 or indices.shape[0] != nnz or data.shape[0] != nnz:
+        raise format_error(f"{path}: truncated payload")
+    if nnz and (int(indptr[-1]) - int(indptr[0]) != nnz):
+        raise format_error(f"{path}: indptr does not cover nnz")
+    return indptr, indices, data, nrows, ncols
+
+
+def write_dense(path: str, A, dtype) -> None:
+    A = np.ascontiguousarray(A, dtype=dtype)
+    if A.ndim == 1:
+        A = A.reshape(-1, 1)
+    with open(path, "wb") as f:
+        f.write(np.array(A.shape, dtype="<u4").tobytes())
+        f.write(A.tobytes())
+
+
+def read_dense(path: str, dtype) -> np.ndarray:
+    if not str(path).endswith(".bin"):
+        raise format_error("File type is not supported.")      # reference src/matrix.hpp:518
+    with open(path, "rb") as f:
+        shape = np.frombuffer(f.read(8), dtype="<u4")
+        if shape.shape[0] != 2:
+            raise format_error(f"{path}: truncated header")
+        n, m = int(shape[0]), int(shape[1])
+        payload = np.fromfile(f, dtype=dtype, count=n * m)
+    if payload.shape[0] != n * m:
+        raise format_error(f"{path}: truncated payload")
+    return payload.reshape(n, m)
+
+
+def write_dataset(dirname: str, indptr, indices, data, features, labels, sets=None) -> None:
+    """Writes graph.bin / features.bin / labels.bin / sets.bin (reference prep.py:78-99)."""
+    os.makedirs(dirname, exist_ok=True)
+    write_csr(os.path.join(dirname, "graph.bin"), indptr, indices, data)
+    write_dense(os.path.join(dirname, "features.bin"), features, "<f4")
+    labels = np.asarray(labels).reshape(-1, 1)
+    write_dense(os.path.join(dirname, "labels.bin"), labels, "<u4")
+    if sets is None:
+        sets = np.zeros_like(labels)
+    write_dense(os.path.join(dirname, "sets.bin"), np.asarray(sets).reshape(-1, 1), "<u4")
+
+
+def read_dataset(dirname: str):
+    """Returns ((indptr, indices, data, n, m), X f32[n,F], Y int32[n,1], S int32[n,1])
+    exactly as reference src/main.cpp:82-85 loads them."""
+    g = read_csr(os.path.join(dirname, "graph.bin"))
+    X = read_dense(os.path.join(dirname, "features.bin"), "<f4")
+    Y = read_dense(os.path.join(dirname, "labels.bin"), "<i4")
+    S = read_dense(os.path.join(dirname, "sets.bin"), "<i4")
+    return g, X, Y, S
+
+
+# ----------------------------------------------------------------------------
+# Synthetic inputs.  Deterministic, numpy only.
+# ----------------------------------------------------------------------------
+def synth_uniform_csr(n: int, deg: int, seed: int = 0):
+    """C1: n rows, exactly ``deg`` distinct random columns per row (nnz = n*deg),
+    values uniform(0,1).  n=10_000, deg=10 is BASELINE.json configs[0]."""
+    rng = np.random.default_rng(seed)
+    cols = np.empty((n, deg), dtype=np.uint32)
+    # distinct columns per row: draw with a stride trick, then fix the rare collisions
+    cols[:] = rng.integers(0, n, size=(n, deg), dtype=np.uint32)
+    cols.sort(axis=1)
+    dup = (np.diff(cols, axis=1) == 0)
+    while dup.any():
+        r, c = np.nonzero(dup)
+        cols[r, c + 1] = rng.integers(0, n, size=r.shape[0], dtype=np.uint32)
+        cols.sort(axis=1)
+        dup = (np.diff(cols, axis=1) == 0)
+    indptr = (np.arange(n + 1, dtype=np.uint64) * deg).astype(np.uint32)
+    data = rng.random(n * deg, dtype=np.float32)
+    return indptr, cols.reshape(-1), data
+
+
+def synth_powerlaw_csr(n: int, nnz_target: int, max_deg: int, seed: int = 1, alpha: float = 1.3,
+                       self_loops: bool = True):
+    """Reddit-shaped stand-in: heavy-tailed out-degrees with the requested
+    total, uniformly random columns (the reference trains on a randomly permuted graph,
+    prep.py:87-94, so columns carry no locality), a self-loop on every row (prep.py:113),
+    unit values (the trainer normalises them).  Duplicate columns inside a row are allowed
+    (they are legal CSR and every consumer handles them); indices are NOT sorted."""
+    rng = np.random.default_rng(seed)
+    # Pareto-like degrees clipped to [1, max_deg], rescaled to hit the nnz target exactly
+    raw = (rng.pareto(alpha, size=n) + 1.0)
+    raw = np.minimum(raw, raw.mean() * max_deg / max(nnz_target / n, 1.0))
+    deg = np.maximum(1, np.floor(raw * (nnz_target / raw.sum()))).astype(np.int64)
+    deg = np.minimum(deg, max_deg)
+    diff = int(nnz_target - deg.sum())
+    # distribute the remainder (or remove the surplus) over random rows, one entry each
+    while diff != 0:
+        k = min(abs(diff), n)
+        rows = rng.choice(n, size=k, replace=False)
+        if diff > 0:
+            ok = rows[deg[rows] < max_deg]
+            deg[ok] += 1
+            diff -= ok.shape[0]
+        else:
+            ok = rows[deg[rows] > 1]
+            deg[ok] -= 1
+            diff += ok.shape[0]
+    indptr = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(deg, out=indptr[1:])
+    assert indptr[-1] == nnz_target and indptr[-1] < 2 ** 32
+    indices = rng.integers(0, n, size=int(nnz_target), dtype=np.uint32)
+    if self_loops:
+        indices[indptr[:-1].astype(np.int64)] = np.arange(n, dtype=np.uint32)
+    data = np.ones(int(nnz_target), dtype=np.float32)
+    return indptr.astype(np.uint32), indices, data
+
+
+REDDIT_SHAPE = dict(n=232_968, nnz=114_848_860, features=608, classes=41, max_deg=21_657)
+
+
+def synth_reddit_like(scale: float = 1.0, seed: int = 1):
+    """Graph + features + labels with Reddit's published shape (reference
+    test/test_matrix.cpp:45-62: n=232 968, nnz=114 848 860, F=608; 41 classes), or a
+    ``scale``d-down version with the same mean degree (n multiple of 8 as prep.py:101-103)."""
+    n = int(REDDIT_SHAPE["n"] * scale) // 8 * 8
+    nnz = int(REDDIT_SHAPE["nnz"] * scale)
+    max_deg = max(8, min(n, int(REDDIT_SHAPE["max_deg"] * min(1.0, scale * 4))))
+    indptr, indices, data = synth_powerlaw_csr(n, nnz, max_deg, seed)
+    rng = np.random.default_rng(seed + 1)
+    X = rng.standard_normal((n, REDDIT_SHAPE["features"]), dtype=np.float32)
+    Y = rng.integers(0, REDDIT_SHAPE["classes"], size=(n, 1)).astype(np.int32)
+    Y[0, 0] = REDDIT_SHAPE["classes"] - 1          # num_labels = 1 + max(Y) (main.cpp:89)
+    return (indptr, indices, data), X, Y

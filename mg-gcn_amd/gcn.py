@@ -1,0 +1,362 @@
+"""Layer API of the reference (src/gcn.hpp) over the HIP engine, single GPU.
+
+``sparse_linear`` (src/gcn.hpp:13-48), ``linear`` (:88-189), ``gcn_layer``
+(:411-518), ``softmax`` (:639-676), ``softmax_cross_entropy_loss`` (:769-823),
+``gcn`` (:937-995) -- same names, constructor arguments, call/backward/
+adam_update members, buffer aliasing and timer names.
+
+``fused=True`` (default for ``gcn``) swaps three launch chains for their fused
+kernels -- identical math, fewer passes:
+  * leaky-ReLU folded into the SpMM epilogue when the SpMM is the layer's last op,
+  * softmax + argmax + log-prob + gradient in one kernel instead of 8 + a GEMM,
+  * one Adam kernel per tensor instead of 4.
+``fused=False`` runs the reference's launch sequence one for one.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import ops
+from .matrix import context, csr_matrix, dn_matrix
+
+MGGCN_SPMM_LEAKY_RELU = 1
+_SQRT_1_3 = float(np.sqrt(np.float32(1.0) / np.float32(3)))     # b.init(std::sqrt((r_t)1.0 / 3)), gcn.hpp:109
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class sparse_linear:
+    """reference src/gcn.hpp:13-48: holds (A, A_T); forward SpMM with A, backward with A_T."""
+
+    def __init__(self, name: str, A: csr_matrix, A_T: csr_matrix):
+        self.name, self.A, self.A_T = name, A, A_T
+        self.M = self.M2 = 0
+        self.ext_buffer = self.ext_buffer2 = None
+        self._max_d = [128, 128]     # plans are sized for at least the reference's hidden width
+
+    def __call__(self, ctx: context, B: dn_matrix, C: dn_matrix, discard: bool = True, flags: int = 0) -> None:
+        if B.m() != self.M:                                   # workspace cached per width, gcn.hpp:28-31
+            self.M = B.m()
+            if self.ext_buffer is None or B.m() > self._max_d[0]:
+                self._max_d[0] = max(B.m(), self._max_d[0])
+                self.ext_buffer = ops.get_matmul_buffer(ctx, self.A, B, C, 1.0, 0.0 if discard else 1.0,
+                                                        max_d=self._max_d[0])
+        n = self.name
+        ctx.record(n + "0_0_matmul-spmm", 0)
+        ops.matmul(ctx, self.A, B, C, self.ext_buffer, 1.0, 0.0 if discard else 1.0, flags)
+        ctx.record(n + "0_1_matmul-spmm", 0)
+        ctx.register_timer(n + "0_matmul-spmm", n + "0_0_matmul-spmm", n + "0_1_matmul-spmm")
+
+    def backward(self, ctx: context, G: dn_matrix, G_out: dn_matrix, discard: bool = True) -> None:
+        if G.m() != self.M2:
+            self.M2 = G.m()
+            if self.ext_buffer2 is None or G.m() > self._max_d[1]:
+                self._max_d[1] = max(G.m(), self._max_d[1])
+                self.ext_buffer2 = ops.get_matmul_buffer(ctx, self.A_T, G, G_out, 1.0, 0.0 if discard else 1.0,
+                                                         max_d=self._max_d[1])
+        n = self.name
+        ctx.record(n + "1_0_matmul-spmm", 0)
+        ops.matmul(ctx, self.A_T, G, G_out, self.ext_buffer2, 1.0, 0.0 if discard else 1.0)
+        ctx.record(n + "1_1_matmul-spmm", 0)
+        ctx.register_timer(n + "1_matmul-spmm", n + "1_0_matmul-spmm", n + "1_1_matmul-spmm")
+
+
+class linear:
+    """reference src/gcn.hpp:88-189: XW = X.W + 1 b^T; backward G_b, G_W, G_out; Adam."""
+
+    def __init__(self, name: str, in_: int, out: int, backward_out: bool = True, fused: bool = False):
+        self.name = name
+        self.W, self.G_W = dn_matrix(in_, out), dn_matrix(in_, out)
+        self.b, self.G_b = dn_matrix(1, out), dn_matrix(1, out)
+        self.backward_out, self.fused = backward_out, fused
+        self.W.init()
+        self.b.init(_SQRT_1_3)
+        self.X: Optional[dn_matrix] = None
+        self.ones: Optional[dn_matrix] = None
+        self.mW = self.vW = self.mb = self.vb = None
+        self.step = 0
+
+    def setX(self, new_X: dn_matrix) -> None:
+        self.X = new_X
+
+    def __call__(self, ctx: context, X: dn_matrix, XW: dn_matrix, discard: bool = True) -> None:
+        n = self.name
+        ops.broadcast_rows(ctx, self.b, XW, discard)
+        ctx.record(n + "0_0_matmul-gemm", 0)
+        ops.matmul(ctx, X, self.W, XW, 1.0, 1.0)
+        ctx.record(n + "0_1_matmul-gemm", 0)
+        ctx.register_timer(n + "0_matmul-gemm", n + "0_0_matmul-gemm", n + "0_1_matmul-gemm")
+        self.X = X
+
+    def backward(self, ctx: context, G: dn_matrix, G_out: Optional[dn_matrix], discard: bool = True) -> None:
+        n = self.name
+        if self.ones is None or self.ones.m() != G.n():
+            self.ones = dn_matrix(1, G.n())
+            ctx.fill(self.ones, 1.0)        # host-side std::fill in the reference (gcn.hpp:127-128)
+        ctx.record(n + "1_0_matmul-gemm", 0)
+        ops.matmul(ctx, self.ones, G, self.G_b, 1.0, 0.0)
+        ctx.record(n + "1_1_matmul-gemm", 0)
+        ops.matmul(ctx, self.X, G, self.G_W, 1.0, 0.0, True)
+        ctx.record(n + "1_2_matmul-gemm", 0)
+        if self.backward_out:
+            ops.matmul(ctx, G, self.W, G_out, 1.0, 0.0 if discard else 1.0, False, True)
+        ctx.record(n + "1_3_matmul-gemm", 0)
+        ctx.register_timer(n + "1_matmul-gemm", n + "1_0_matmul-gemm", n + "1_3_matmul-gemm")
+
+    def update(self, ctx: context, lr: float, weight_decay: float) -> None:      # gcn.hpp:141-144
+        ops.axpby(ctx, self.G_W, self.W, -lr, 1 - weight_decay)
+        ops.axpy(ctx, self.G_b, self.b, -lr)
+
+    def adam_update(self, ctx: context, lr: float, beta1: float, beta2: float, weight_decay: float,
+                    eps: float) -> None:
+        if self.mW is None:
+            self.mW, self.vW = dn_matrix(self.W.shape()), dn_matrix(self.W.shape())
+            self.mb, self.vb = dn_matrix(self.b.shape()), dn_matrix(self.b.shape())
+            for t in (self.mW, self.vW, self.mb, self.vb):
+                t.zero(ctx)
+            self.step = 0
+        self.step += 1
+        bc1 = float(np.float32(1 - beta1 ** self.step))
+        bc2 = float(np.float32(1 - beta2 ** self.step))
+        n = self.name
+        ctx.record(n + "0_adam-update", 0)
+        if self.fused:
+            ops.adam_fused(ctx, self.W, self.G_W, self.mW, self.vW, lr, beta1, beta2, weight_decay, bc1, bc2, eps)
+            ops.adam_fused(ctx, self.b, self.G_b, self.mb, self.vb, lr, beta1, beta2, 0.0, bc1, bc2, eps)
+        else:
+            ops.axpy(ctx, self.W, self.G_W, weight_decay)
+            ops.axpby(ctx, self.G_W, self.mW, 1 - beta1, beta1)
+            ops.axpby(ctx, self.G_b, self.mb, 1 - beta1, beta1)
+            ops.aaxpby(ctx, self.G_W, self.vW, 1 - beta2, beta2)
+            ops.aaxpby(ctx, self.G_b, self.vb, 1 - beta2, beta2)
+            ops.adam_final(ctx, self.W, self.mW, self.vW, lr, bc1, bc2, eps)
+            ops.adam_final(ctx, self.b, self.mb, self.vb, lr, bc1, bc2, eps)
+        ctx.record(n + "1_adam-update", 0)
+        ctx.register_timer(n + "adam-update", n + "0_adam-update", n + "1_adam-update")
+
+    def get_b(self): return self.b
+    def get_W(self): return self.W
+    def get_G_W(self): return self.G_W
+    def get_G_b(self): return self.G_b
+
+
+class gcn_layer:
+    """reference src/gcn.hpp:411-518.  HW / G_HW alias the model-wide HW_buffer,
+    AHW / G_out alias the layer's AHW_buffer (:433-434)."""
+
+    def __init__(self, name: str, A: csr_matrix, A_T: csr_matrix, in_: int, out: int, activation: bool,
+                 residual_layer: bool = False, backward_spmm: bool = True, HW_buffer=None, fused: bool = False):
+        torch = _torch()
+        if residual_layer:
+            raise NotImplementedError("residual_layer is never enabled by the reference CLI (SURVEY.md 8(f) rank 4)")
+        self.name = name
+        self.A = sparse_linear(name, A, A_T)
+        self.lin = linear(name, in_, out, backward_spmm, fused)
+        mn = min(in_, out)
+        if HW_buffer is None:
+            HW_buffer = torch.empty(max(A.m(), A_T.n()) * mn, dtype=torch.float32, device="cuda")
+        self.AHW_buffer = torch.empty(max(A.n() * out, A_T.n() * in_), dtype=torch.float32, device="cuda")
+        self.HW = dn_matrix(A.m(), mn, HW_buffer)
+        self.AHW = dn_matrix(A.n(), out, self.AHW_buffer)
+        self.G_HW = dn_matrix(A_T.n(), mn, HW_buffer)
+        self.G_out = dn_matrix(A_T.n(), in_, self.AHW_buffer)
+        self.activation, self.backward_spmm, self.fused = activation, backward_spmm, fused
+        self.H: Optional[dn_matrix] = None
+
+    def __call__(self, ctx: context, H: dn_matrix) -> dn_matrix:
+        self.H = H
+        n = self.name
+        act_done = False
+        if self.HW.m() == self.AHW.m():           # out <= in: GEMM first (gcn.hpp:439-442)
+            self.lin(ctx, H, self.HW)
+            if self.fused and self.activation:
+                self.A(ctx, self.HW, self.AHW, True, MGGCN_SPMM_LEAKY_RELU)
+                act_done = True
+            else:
+                self.A(ctx, self.HW, self.AHW)
+        else:                                      # gcn.hpp:443-446
+            self.A(ctx, H, self.HW)
+            self.lin(ctx, self.HW, self.AHW)
+        if self.activation and not act_done:
+            ctx.record(n + "0_0_activation", 0)
+            ops.leaky_relu_forward(ctx, self.AHW, self.AHW)
+            ctx.record(n + "0_1_activation", 0)
+            ctx.register_timer(n + "0_activation", n + "0_0_activation", n + "0_1_activation")
+        return self.AHW
+
+    def backward(self, ctx: context, G: dn_matrix) -> dn_matrix:
+        n = self.name
+        T = G
+        if self.activation:
+            ctx.record(n + "1_0_activation", 0)
+            ops.leaky_relu_backward(ctx, self.AHW, G, self.AHW)
+            ctx.record(n + "1_1_activation", 0)
+            ctx.register_timer(n + "1_activation", n + "1_0_activation", n + "1_1_activation")
+            T = self.AHW
+        if self.HW.m() == self.AHW.m():
+            G_HW = self.G_HW
+            if self.backward_spmm:
+                self.A.backward(ctx, T, G_HW)
+            else:
+                G_HW = T
+            self.lin.backward(ctx, G_HW, self.G_out)
+            return self.G_out
+        self.lin.setX(self.H)
+        self.lin.backward(ctx, T, self.G_HW)
+        if self.backward_spmm:
+            self.A.backward(ctx, self.G_HW, self.G_out)
+            return self.G_out
+        return self.G_HW
+
+    def update(self, ctx, lr, weight_decay): self.lin.update(ctx, lr, weight_decay)
+
+    def adam_update(self, ctx, lr, beta1, beta2, weight_decay, eps):
+        self.lin.adam_update(ctx, lr, beta1, beta2, weight_decay, eps)
+
+    def b(self): return self.lin.get_b()
+    def W(self): return self.lin.get_W()
+    def GW(self): return self.lin.get_G_W()
+    def Gb(self): return self.lin.get_G_b()
+
+
+class softmax:
+    """reference src/gcn.hpp:639-676: row max, exp(x - max), row sums via a GEMM with a
+    ones vector, divide."""
+
+    def __init__(self, copy: bool = True):
+        self.copy = copy
+        self.H = self.H_R = self.maxs = self.ones = None
+
+    def __call__(self, ctx: context, temp: dn_matrix) -> dn_matrix:
+        if self.copy:
+            if self.H is None:
+                self.H = dn_matrix(temp.n(), temp.m())
+            temp.copy_to(ctx, self.H)
+        else:
+            self.H = temp
+        H = self.H
+        if self.maxs is None:
+            self.maxs = dn_matrix(H.n(), 1)
+        ops.max_rows(ctx, H, self.maxs)
+        ops.subtract_rows_exp(ctx, H, self.maxs, H)
+        if self.ones is None:
+            self.ones = dn_matrix(H.m(), 1)
+            ctx.fill(self.ones, 1.0)
+        if self.H_R is None:
+            self.H_R = dn_matrix(H.n(), 1)
+        ops.matmul(ctx, H, self.ones, self.H_R, 1.0, 0.0)
+        ops.scale_rows(ctx, H, self.H_R)
+        return H
+
+
+class softmax_cross_entropy_loss:
+    """reference src/gcn.hpp:769-823.  Returns (loss, acc) = (sum|log p_y|, #correct) / n
+    after a device sync, exactly where the reference blocks (:816-817)."""
+
+    def __init__(self, name: str, copy: bool = True, fused: bool = False):
+        self.name = name
+        self.softmax_layer = softmax(copy)
+        self.copy, self.fused = copy, fused
+        self.G = self.L = self.P = self.T = None
+        self.sums = None
+
+    def __call__(self, ctx: context, H: dn_matrix, Y: dn_matrix, n_global: Optional[int] = None,
+                 sync: bool = True):
+        torch = _torch()
+        n = self.name
+        if n_global is None:
+            n_global = Y.n()
+        ctx.record(n + "0_loss-layer", 0)
+        if self.sums is None:
+            self.sums = torch.empty(2, dtype=torch.float32, device=ctx.device)
+        if self.fused:
+            if self.copy:
+                if self.G is None:
+                    self.G = dn_matrix(H.n(), H.m())
+                H.copy_to(ctx, self.G)
+            else:
+                self.G = H
+            ctx.lib.mggcn_memset_zero(self.sums.data_ptr(), 8, ctx.stream(0))
+            ops.softmax_xent_fused(ctx, self.G, Y, 1.0 / n_global, self.sums)
+        else:
+            O = self.softmax_layer(ctx, H)
+            if self.P is None:
+                self.P = dn_matrix(Y.shape(), dtype=np.int32)
+            ops.max_row_indices(ctx, O, self.P)
+            if self.L is None:
+                self.L = dn_matrix(Y.shape())
+            ops.index_log_rows(ctx, O, Y, self.L)
+            self.G = O
+            ops.add_indexed_rows(ctx, self.G, Y, -1.0)
+            ops.scale_mat(ctx, self.G, float(np.float32(1) / np.float32(n_global)))
+            if self.T is None:
+                self.T = dn_matrix(Y.shape())
+            ops.is_equal(ctx, Y, self.P, self.T)
+            ops.abssum(ctx, self.L, self.sums[0:1])
+            ops.abssum(ctx, self.T, self.sums[1:2])
+        ctx.record(n + "1_loss-layer", 0)
+        ctx.register_timer(n + "loss-layer", n + "0_loss-layer", n + "1_loss-layer")
+        if not sync:
+            return None
+        ctx.sync()
+        s = self.sums.cpu().numpy()
+        return float(np.float32(s[0]) / np.float32(H.n())), float(np.float32(s[1]) / np.float32(H.n()))
+
+    def backward(self) -> dn_matrix:
+        return self.G
+
+
+class gcn:
+    """reference src/gcn.hpp:937-995.  The constructor column-normalises A, builds
+    A_T and hands (A_T, A) to the layers -- forward multiplies by A_T (:946-955)."""
+
+    def __init__(self, A: csr_matrix, sizes: Sequence[int], residual_layer: bool = False,
+                 weights: Optional[List[Tuple[np.ndarray, np.ndarray]]] = None, fused: bool = True):
+        torch = _torch()
+        self.fused = fused
+        self.loss_layer = softmax_cross_entropy_loss(f"{len(sizes) - 1}_", residual_layer, fused)
+        A.normalize(True)
+        A_T = A.transpose()
+        self.A, self.A_T = A, A_T
+        max_d = max(min(sizes[i], sizes[i + 1]) for i in range(len(sizes) - 1))
+        self.HW_buffer = torch.empty(max(A.n(), A.m()) * max_d, dtype=torch.float32, device="cuda")
+        self.layers_: List[gcn_layer] = []
+        for i in range(1, len(sizes)):
+            self.layers_.append(gcn_layer(f"{i - 1}_", A_T, A, sizes[i - 1], sizes[i], i + 1 < len(sizes),
+                                          residual_layer, i != 1, self.HW_buffer, fused))
+        if weights is not None:                     # test constructor, gcn.hpp:957-963
+            assert len(weights) == len(self.layers_)
+            for layer, (W, b) in zip(self.layers_, weights):
+                layer.W().init(np.asarray(W, dtype=np.float32))
+                layer.b().init(np.asarray(b, dtype=np.float32))
+
+    def __call__(self, ctx: context, H: dn_matrix) -> dn_matrix:
+        for layer in self.layers_:
+            H = layer(ctx, H)
+        return H
+
+    def train_forward(self, ctx: context, H: dn_matrix, Y: dn_matrix):
+        H = self(ctx, H)
+        return self.loss_layer(ctx, H, Y)
+
+    def backward(self, ctx: context) -> None:
+        G = self.loss_layer.backward()
+        for layer in reversed(self.layers_):
+            G = layer.backward(ctx, G)
+
+    def update(self, ctx: context, lr: float, weight_decay: float) -> None:
+        for layer in self.layers_:
+            layer.update(ctx, lr, weight_decay)
+
+    def adam_update(self, ctx: context, lr: float, beta1: float, beta2: float, weight_decay: float,
+                    eps: float) -> None:
+        for layer in self.layers_:
+            layer.adam_update(ctx, lr, beta1, beta2, weight_decay, eps)
+
+    def layers(self) -> List[gcn_layer]:
+        return self.layers_

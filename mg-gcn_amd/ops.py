@@ -1,0 +1,184 @@
+"""The reference's operator overload set (src/cuda_utils.hpp) over the C ABI.
+
+Same function names, argument order and meaning as the reference's free
+functions taking ``(context, matrix objects...)``; each one enqueues exactly one
+C-ABI call on ``ctx.cuda_streams[0]`` (the reference's compute stream).
+Shape preconditions the reference only ``assert``s raise ``ValueError`` here.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+from .matrix import context, csr_matrix, dn_matrix
+
+
+def _req(cond: bool, what: str) -> None:
+    if not cond:
+        raise ValueError(what)
+
+
+class spmm_buffer:
+    """What get_matmul_buffer returns: the reference's opaque cuSPARSE workspace
+    (src/cuda_utils.hpp:94-102) becomes the row-split plan of the HIP kernel."""
+
+    def __init__(self, lib, handle: int):
+        self.lib, self.handle = lib, handle
+
+    def num_items(self) -> int: return self.lib.mggcn_spmm_plan_num_items(self.handle)
+    def num_split_rows(self) -> int: return self.lib.mggcn_spmm_plan_num_split_rows(self.handle)
+    def nbytes(self) -> int: return self.lib.mggcn_spmm_plan_bytes(self.handle)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.mggcn_spmm_plan_destroy(self.handle)
+                self.handle = 0
+        except Exception:
+            pass
+
+
+def get_matmul_buffer(ctx: context, A: csr_matrix, B: dn_matrix, C: dn_matrix, alpha: float = 1.0,
+                      beta: float = 0.0, max_d: Optional[int] = None) -> spmm_buffer:
+    """reference src/cuda_utils.hpp:94-102"""
+    _req(A.m() == B.n(), "A.m() != B.n()")
+    _req(A.n() == C.n() and B.m() == C.m(), "C shape mismatch")
+    ctx.set()
+    h = ctx.lib.mggcn_spmm_plan_create(A.n(), A.m(), A.indptr.ctypes.data, max(int(max_d or 0), B.m()))
+    return spmm_buffer(ctx.lib, h)
+
+
+def matmul(ctx: context, A, B: dn_matrix, C: dn_matrix, *args, **kw) -> None:
+    """Overloads, as in the reference:
+       matmul(ctx, csr A, B, C, ext_buffer, alpha, beta)        src/cuda_utils.hpp:27-32
+       matmul(ctx, dn  A, B, C, alpha, beta, A_T=False, B_T=False)  src/cuda_utils.hpp:158-172"""
+    if isinstance(A, csr_matrix):
+        return _spmm(ctx, A, B, C, *args, **kw)
+    return _gemm(ctx, A, B, C, *args, **kw)
+
+
+def _spmm(ctx: context, A: csr_matrix, B: dn_matrix, C: dn_matrix, ext_buffer: Optional[spmm_buffer],
+          alpha: float, beta: float, flags: int = 0, slope: float = 0.01, stream_id: int = 0) -> None:
+    _req(A.m() == B.n() and B.m() == C.m() and A.n() == C.n(), "SpMM shape mismatch")
+    ctx.set()
+    ip, ix, dv = A.device(ctx.device)
+    ctx.lib.mggcn_spmm_csr_f32(ctx.stream(stream_id), ext_buffer.handle if ext_buffer else None, A.n(), A.m(),
+                               ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), B.buffer(), B.m(), C.buffer(),
+                               C.m(), B.m(), alpha, beta, flags, slope)
+
+
+def _gemm(ctx: context, A: dn_matrix, B: dn_matrix, C: dn_matrix, alpha: float, beta: float,
+          A_T: bool = False, B_T: bool = False) -> None:
+    A_n, A_m, B_n, B_m = A.n(), A.m(), B.n(), B.m()
+    if A_T:
+        A_n, A_m = A_m, A_n
+    if B_T:
+        B_n, B_m = B_m, B_n
+    _req(A_m == B_n, "GEMM inner dimensions differ")
+    _req(A_n == C.n() and B_m == C.m(), "GEMM output shape mismatch")
+    ctx.set()
+    ws_bytes = ctx.lib.mggcn_gemm_workspace_bytes(int(A_T), int(B_T), A_n, B_m, A_m)
+    ws = ctx.workspace(ws_bytes)
+    ctx.lib.mggcn_gemm_f32(ctx.stream(0), int(A_T), int(B_T), A_n, B_m, A_m, alpha, A.buffer(), A.m(),
+                           B.buffer(), B.m(), beta, C.buffer(), C.m(), ws.data_ptr() if ws is not None else None,
+                           ws_bytes)
+
+
+# ---- element-wise / row kernels: src/cuda_utils.hpp:470-748 wrappers -----------------
+def leaky_relu_forward(ctx: context, in_: dn_matrix, out: dn_matrix, alpha: float = 0.01) -> None:
+    _req(in_.shape() == out.shape(), "shape mismatch")
+    ctx.lib.mggcn_leaky_relu_forward_f32(ctx.stream(0), in_.buffer(), out.buffer(), in_.size(), alpha)
+
+
+def leaky_relu_backward(ctx: context, in_: dn_matrix, G_in: dn_matrix, G_out: dn_matrix,
+                        alpha: float = 0.01) -> None:
+    _req(in_.shape() == G_in.shape() == G_out.shape(), "shape mismatch")
+    ctx.lib.mggcn_leaky_relu_backward_f32(ctx.stream(0), in_.buffer(), G_in.buffer(), G_out.buffer(),
+                                          in_.size(), alpha)
+
+
+def broadcast_rows(ctx: context, row: dn_matrix, mat: dn_matrix, discard: bool = True) -> None:
+    _req(row.m() == mat.m(), "row width mismatch")
+    ctx.lib.mggcn_broadcast_rows_f32(ctx.stream(0), row.buffer(), mat.buffer(), mat.size(), mat.m(), int(discard))
+
+
+def scale_rows(ctx: context, mat: dn_matrix, scalar: dn_matrix) -> None:
+    _req(mat.n() == scalar.n(), "row count mismatch")
+    ctx.lib.mggcn_scale_rows_f32(ctx.stream(0), mat.buffer(), scalar.buffer(), mat.size(), mat.m())
+
+
+def max_rows(ctx: context, mat: dn_matrix, maxs: dn_matrix) -> None:
+    _req(mat.n() == maxs.n() and maxs.m() == 1, "maxs must be n x 1")
+    ctx.lib.mggcn_max_rows_f32(ctx.stream(0), mat.buffer(), maxs.buffer(), mat.size(), mat.m())
+
+
+def max_row_indices(ctx: context, mat: dn_matrix, maxs: dn_matrix) -> None:
+    _req(mat.n() == maxs.n() and maxs.m() == 1, "maxs must be n x 1")
+    ctx.lib.mggcn_max_row_indices_f32(ctx.stream(0), mat.buffer(), maxs.buffer(), mat.size(), mat.m())
+
+
+def index_log_rows(ctx: context, mat: dn_matrix, indices: dn_matrix, values: dn_matrix) -> None:
+    _req(mat.n() == indices.n() and indices.m() == 1 and values.n() == mat.n() and values.m() == 1, "shape")
+    ctx.lib.mggcn_index_log_rows_f32(ctx.stream(0), mat.buffer(), indices.buffer(), values.buffer(), mat.size(),
+                                     mat.m())
+
+
+def add_indexed_rows(ctx: context, mat: dn_matrix, indices: dn_matrix, alpha: float) -> None:
+    _req(mat.n() == indices.n() and indices.m() == 1, "shape")
+    ctx.lib.mggcn_add_indexed_rows_f32(ctx.stream(0), mat.buffer(), indices.buffer(), alpha, mat.size(), mat.m())
+
+
+def is_equal(ctx: context, mat1: dn_matrix, mat2: dn_matrix, out: dn_matrix) -> None:
+    _req(mat1.shape() == mat2.shape() == out.shape(), "shape mismatch")
+    ctx.lib.mggcn_is_equal_i32(ctx.stream(0), mat1.buffer(), mat2.buffer(), out.buffer(), mat1.size())
+
+
+def subtract_rows_exp(ctx: context, mat: dn_matrix, scalar: dn_matrix, out: dn_matrix) -> None:
+    _req(mat.n() == scalar.n() and scalar.m() == 1 and mat.shape() == out.shape(), "shape")
+    ctx.lib.mggcn_subtract_rows_exp_f32(ctx.stream(0), mat.buffer(), scalar.buffer(), out.buffer(), mat.size(),
+                                        mat.m())
+
+
+def axpy(ctx: context, A: dn_matrix, B: dn_matrix, alpha: float) -> None:
+    _req(A.shape() == B.shape(), "shape mismatch")
+    ctx.lib.mggcn_axpy_f32(ctx.stream(0), A.buffer(), B.buffer(), alpha, A.size())
+
+
+def axpby(ctx: context, A: dn_matrix, B: dn_matrix, alpha: float, beta: float) -> None:
+    _req(A.shape() == B.shape(), "shape mismatch")
+    ctx.lib.mggcn_axpby_f32(ctx.stream(0), A.buffer(), B.buffer(), alpha, beta, A.size())
+
+
+def aaxpby(ctx: context, A: dn_matrix, B: dn_matrix, alpha: float, beta: float) -> None:
+    _req(A.shape() == B.shape(), "shape mismatch")
+    ctx.lib.mggcn_aaxpby_f32(ctx.stream(0), A.buffer(), B.buffer(), alpha, beta, A.size())
+
+
+def adam_final(ctx: context, param: dn_matrix, m: dn_matrix, v: dn_matrix, lr: float, c1: float, c2: float,
+               eps: float) -> None:
+    _req(param.shape() == m.shape() == v.shape(), "shape mismatch")
+    ctx.lib.mggcn_adam_final_f32(ctx.stream(0), param.buffer(), m.buffer(), v.buffer(), lr, c1, c2, eps,
+                                 param.size())
+
+
+def scale_mat(ctx: context, mat: dn_matrix, scalar: float) -> None:
+    ctx.lib.mggcn_scale_mat_f32(ctx.stream(0), mat.buffer(), scalar, mat.size())
+
+
+def abssum(ctx: context, A: dn_matrix, result_device) -> None:
+    """cublasSasum (src/cuda_utils.hpp:362-371).  ``result_device``: 1-element float32
+    device tensor; enqueue-only (the reference's call blocks the host)."""
+    ctx.lib.mggcn_abssum_f32(ctx.stream(0), A.buffer(), A.size(), result_device.data_ptr())
+
+
+# ---- fused tail ------------------------------------------------
+def softmax_xent_fused(ctx: context, H: dn_matrix, Y: dn_matrix, grad_scale: float, sums_device) -> None:
+    _req(H.n() == Y.n() and Y.m() == 1, "labels must be n x 1")
+    ctx.lib.mggcn_softmax_xent_fused_f32(ctx.stream(0), H.buffer(), Y.buffer(), H.n(), H.m(), grad_scale,
+                                         sums_device.data_ptr())
+
+
+def adam_fused(ctx: context, param: dn_matrix, grad: dn_matrix, m: dn_matrix, v: dn_matrix, lr: float,
+               beta1: float, beta2: float, weight_decay: float, c1: float, c2: float, eps: float) -> None:
+    _req(param.shape() == grad.shape() == m.shape() == v.shape(), "shape mismatch")
+    ctx.lib.mggcn_adam_fused_f32(ctx.stream(0), param.buffer(), grad.buffer(), m.buffer(), v.buffer(), lr,
+                                 beta1, beta2, weight_decay, c1, c2, eps, param.size())

@@ -1,0 +1,230 @@
+"""Pins the CPU oracle against every known-answer test and fixture the reference's
+own tests hold for the hot path:
+
+  test/test_gcn.cpp:98-115   test_cross_entropy   loss 1.146482 + 9 gradients
+  test/test_gcn.cpp:118-139  test_leaky_relu      loss 0.8637248 + 9 gradients
+  test/test_gcn.cpp:141-193  test_g               dense-A chain
+  test/test_gcn.cpp:195-249  test_csr_g           the one asserted test through the SpMM
+  test/test_matrix.cpp:11-43 toyA/toyB shapes, :64-76 csr_to_dn, :93-109 csr transpose
+
+The reference's ASSERT_CLOSE is |log2 x - log2 y| <= 1e-4 (test/test.hpp:39-46), which
+passes vacuously for negative numbers; here the same numbers are checked with a real
+relative tolerance of the same size (7e-5) plus the literals' own rounding (5e-8).
+"""
+import os
+
+import numpy as np
+import pytest
+
+RTOL = 7e-5
+ATOL = 6e-8
+
+
+def close(x, y):
+    np.testing.assert_allclose(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64),
+                               rtol=RTOL, atol=ATOL)
+
+
+LOGITS = np.array([[2, 1, 2], [4, 2, 1], [1, -1, 0]], dtype=np.float32)
+Y3 = np.array([0, 0, 1], dtype=np.int32)
+
+
+def test_cross_entropy_kat(oracle):
+    ls, ac, G, _ = oracle.softmax_cross_entropy(LOGITS.copy(), Y3)
+    close(ls / 3, 1.146482)
+    close(G.reshape(-1), [-0.1925604, 0.0517875, 0.1407729, -0.0520684, 0.0380651, 0.0140034,
+                          0.2217470, -0.3033231, 0.0815762])
+    assert ac == 2.0        # rows 0 (tie -> first max) and 1 are predicted as class 0
+
+
+def test_leaky_relu_kat(oracle):
+    H = oracle.leaky_relu_forward(LOGITS)
+    ls, _, G, _ = oracle.softmax_cross_entropy(H, Y3)
+    # the reference passes the PRE-activation logits as `in` here (test_gcn.cpp:133)
+    G = oracle.leaky_relu_backward(LOGITS, G)
+    close(ls / 3, 0.8637248)
+    close(G.reshape(-1), [-0.1925604, 0.0517875, 0.1407729, -0.0520684, 0.0380651, 0.0140034,
+                          0.1924448, -0.0026324, 0.0007080])
+
+
+X23 = np.array([[4, 2, 1], [1, -1, 0]], dtype=np.float32)
+W32 = np.array([[1, 2], [-1, 0], [0.5, 1.5]], dtype=np.float32)
+B12 = np.array([[1, 0.5]], dtype=np.float32)
+Y2 = np.array([0, 1], dtype=np.int32)
+EXP_G = [-0.4992494, 0.4992494, 0.0237129, -0.0237129]
+EXP_GB = [-0.4755365, 0.4755365]
+EXP_GW = [-1.9377153, 1.9377153, -0.9866424, 0.9866424, -0.4873929, 0.4873929]
+EXP_GOUT = [0.4873929, 0.4873929, 0.4873930, -0.0118565, -0.0118565, -0.0118565]
+
+
+def _chain(oracle, a_mul, at_mul):
+    XW = oracle.gemm(X23, W32)
+    AXW = np.repeat(B12, 2, axis=0).copy()                   # broadcast_rows(b, AXW)
+    AXW = a_mul(XW, AXW)                                     # AXW = A.XW + AXW  (beta = 1)
+    H = oracle.leaky_relu_forward(AXW)
+    ls, _, G, _ = oracle.softmax_cross_entropy(H, Y2)
+    G = oracle.leaky_relu_backward(AXW, G)
+    G_b = oracle.gemm(np.ones((1, 2), dtype=np.float32), G)
+    G_XW = at_mul(G)
+    G_W = oracle.gemm(X23, G_XW, A_T=True)
+    G_out = oracle.gemm(G_XW, W32, B_T=True)
+    return ls / 2, G, G_b, G_W, G_out
+
+
+def _check_chain(res):
+    loss, G, G_b, G_W, G_out = res
+    close(loss, 3.2750449)
+    close(G.reshape(-1), EXP_G)
+    close(G_b.reshape(-1), EXP_GB)
+    close(G_W.reshape(-1), EXP_GW)
+    close(G_out.reshape(-1), EXP_GOUT)
+
+
+def test_g_dense_kat(oracle):
+    A = np.array([[1, 0], [0.5, 0.5]], dtype=np.float32)
+    _check_chain(_chain(oracle, lambda XW, C: oracle.gemm(A, XW, C, 1.0, 1.0),
+                        lambda G: oracle.gemm(A, G, A_T=True)))
+
+
+def test_csr_g_kat(oracle):
+    A = oracle.Csr([0, 1, 3], [0, 0, 1], [1, 0.5, 0.5], 2)
+    At = oracle.transpose(A)
+    _check_chain(_chain(oracle, lambda XW, C: oracle.spmm(A, XW, C, 1.0, 1.0),
+                        lambda G: oracle.spmm(At, G)))
+
+
+def _load(pkg, golden_dir, name):
+    ip, ix, dv, n, m = pkg.datasets.read_csr(os.path.join(golden_dir, name, "graph.bin"))
+    return ip, ix, dv, n, m
+
+
+def test_toy_fixture_shapes(pkg, golden_dir):
+    ip, ix, dv, n, m = _load(pkg, golden_dir, "toyA")
+    assert (n, m, len(ix)) == (4, 4, 8)
+    ip, ix, dv, n, m = _load(pkg, golden_dir, "toyB")
+    assert (n, m, len(ix)) == (4, 4, 12)
+    X = pkg.datasets.read_dense(os.path.join(golden_dir, "toyA", "features.bin"), "<f4")
+    assert X.shape == (4, 2)
+    (g, X, Y, S) = pkg.datasets.read_dataset(os.path.join(golden_dir, "toyB"))
+    assert Y.dtype == np.int32 and Y.reshape(-1).tolist() == [0, 1, 0, 1] and S.reshape(-1).tolist() == [0, 0, 1, 2]
+
+
+def test_csr_to_dn_kat(oracle, pkg, golden_dir):
+    ip, ix, dv, n, m = _load(pkg, golden_dir, "toyA")
+    dn = oracle.as_dn(oracle.Csr(ip, ix, dv, m))
+    assert dn.reshape(-1).tolist() == [0, 1, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1, 1, 0, 1, 0]
+
+
+@pytest.mark.parametrize("name", ["toyA", "toyB"])
+def test_csr_transpose_kat(oracle, pkg, golden_dir, name):
+    ip, ix, dv, n, m = _load(pkg, golden_dir, name)
+    A = oracle.Csr(ip, ix, dv * np.arange(1, len(dv) + 1, dtype=np.float32), m)   # asymmetric values
+    np.testing.assert_array_equal(oracle.as_dn(oracle.transpose(A)), oracle.as_dn(A).T)
+
+
+def test_normalize_matches_definition(oracle):
+    rng = np.random.default_rng(0)
+    dense = (rng.random((7, 5)) < 0.5) * rng.random((7, 5))
+    dense[:, 2] = 0; dense[3, 2] = 0.25          # a column with a single entry
+    dense = dense.astype(np.float32)
+    import scipy.sparse as sp
+    S = sp.csr_matrix(dense)
+    A = oracle.Csr(S.indptr, S.indices, S.data.copy(), 5)
+    oracle.normalize(A, True)
+    col = dense.sum(axis=0); col[col == 0] = 1
+    np.testing.assert_allclose(oracle.as_dn(A), dense / col, rtol=1e-6)
+    B = oracle.Csr(S.indptr, S.indices, S.data.copy(), 5)
+    oracle.normalize(B, False)
+    row = dense.sum(axis=1, keepdims=True); row[row == 0] = 1
+    np.testing.assert_allclose(oracle.as_dn(B), dense / row, rtol=1e-6)
+
+
+def test_spmm_gemm_against_scipy(oracle):
+    """independent cross-check of the C restatement (SURVEY.md 8(c) 'oracle the build will use')"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(1)
+    for n, m, d, dens in [(50, 40, 128, 0.2), (33, 33, 41, 0.5), (10, 12, 1, 0.9), (8, 8, 608, 0.3)]:
+        M = sp.random(n, m, density=dens, format="csr", dtype=np.float32, random_state=2)
+        B = rng.standard_normal((m, d)).astype(np.float32)
+        C0 = rng.standard_normal((n, d)).astype(np.float32)
+        A = oracle.Csr(M.indptr, M.indices, M.data, m)
+        want = 0.5 * (M.astype(np.float64) @ B.astype(np.float64)) + 2.0 * C0
+        got = oracle.spmm(A, B, C0.copy(), 0.5, 2.0)
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+        got64 = oracle.spmm(A, B, C0.copy(), 0.5, 2.0, f64acc=True)
+        np.testing.assert_allclose(got64, want, rtol=1e-6, atol=1e-6)
+    A_ = rng.standard_normal((9, 7)).astype(np.float32); B_ = rng.standard_normal((7, 5)).astype(np.float32)
+    np.testing.assert_allclose(oracle.gemm(A_, B_), A_ @ B_, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(oracle.gemm(A_, A_, A_T=True), A_.T @ A_, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(oracle.gemm(B_, B_, B_T=True), B_ @ B_.T, rtol=1e-5, atol=1e-5)
+
+
+def test_spmm_beta_zero_ignores_garbage(oracle):
+    A = oracle.Csr([0, 1, 1, 3], [1, 0, 2], [2.0, 1.0, 1.0], 3)      # row 1 is empty
+    B = np.arange(6, dtype=np.float32).reshape(3, 2)
+    C = np.full((3, 2), np.nan, dtype=np.float32)
+    out = oracle.spmm(A, B, C, 1.0, 0.0)
+    np.testing.assert_array_equal(out, [[4, 6], [0, 0], [4, 6]])
+
+
+def test_block_split_reassembles(oracle):
+    import scipy.sparse as sp
+    M = sp.random(24, 24, density=0.3, format="csr", dtype=np.float32, random_state=5)
+    A = oracle.Csr(M.indptr, M.indices, M.data, 24)
+    p = [0, 8, 16, 24]
+    blocks = oracle.block_split(A, p, p)
+    dense = oracle.as_dn(A)
+    for i in range(3):
+        for j in range(3):
+            blk = blocks[i][j]
+            assert (blk.n, blk.m) == (8, 8)
+            np.testing.assert_array_equal(oracle.as_dn(blk), dense[p[i]:p[i + 1], p[j]:p[j + 1]])
+    # within-row order preserved (dist_matrix.hpp:244-252)
+    r0 = M.indices[M.indptr[0]:M.indptr[1]]
+    got = np.concatenate([blocks[0][j].indices[blocks[0][j].indptr[0]:blocks[0][j].indptr[1]] + p[j]
+                          for j in range(3)])
+    assert sorted(got.tolist()) == sorted(r0.tolist())
+
+
+def test_weight_init_is_libstdcxx_minstd(oracle):
+    """dn_matrix::init (matrix.hpp:539-545): minstd_rand0 seeded 99, one draw per element."""
+    W = oracle.init_uniform(3, 2)
+    g = np.float32(np.sqrt(2 / (1 + 0.01 * 0.01))) * np.float32(np.sqrt(3.0 / 3))
+    x = 99
+    want = []
+    for _ in range(6):
+        x = (x * 16807) % 2147483647
+        u = np.float32(np.float32(x - 1) / np.float32(2147483646.0))
+        want.append(np.float32(u * (g - (-g)) + (-g)))
+    np.testing.assert_allclose(W.reshape(-1), want, rtol=3e-7)
+    b = oracle.init_uniform(1, 4, oracle.gain_b())
+    assert np.all(np.abs(b) <= 1.0 + 1e-6)
+
+
+def test_dist_oracle_matches_single(oracle):
+    """C_j = sum_i A[j,i] B_i (cuda_utils.hpp:47-92) == rows of A.B; P-shard training
+    == single-GPU training with the same padded class count."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(7)
+    n, P = 32, 4
+    M = sp.random(n, n, density=0.3, format="csr", dtype=np.float32, random_state=8) + sp.eye(n, dtype=np.float32, format="csr")
+    M = sp.csr_matrix(M)
+    A = oracle.Csr(M.indptr, M.indices, M.data, n)
+    p = [i * n // P for i in range(P + 1)]
+    B = rng.standard_normal((n, 16)).astype(np.float32)
+    blocks = oracle.block_split(A, p, p)
+    Cs = oracle.dist_spmm(blocks, [B[p[j]:p[j + 1]] for j in range(P)])
+    np.testing.assert_allclose(np.vstack(Cs), oracle.spmm(A, B), rtol=1e-5, atol=1e-6)
+
+    X = rng.standard_normal((n, 12)).astype(np.float32)
+    Y = rng.integers(0, 5, size=(n, 1)).astype(np.int32)
+    sizes = [12, 8, 8, 5]
+    D = oracle.DistGcn(A, sizes, P)
+    S = oracle.Gcn(A, sizes[:-1] + [8])              # 5 classes padded to 8 = multiple of 4
+    for _ in range(2):
+        dl, da = D.train_forward(X, Y); D.backward(); D.adam_update()
+        sl, sa = S.train_forward(X, Y); S.backward(); S.adam_update()
+        assert abs(dl - sl) <= 1e-5 * abs(sl) and abs(da - sa) < 1e-6
+    for r in range(P):
+        for a, b in zip(D.ranks[r], S.layers):
+            np.testing.assert_allclose(a.lin.W, b.lin.W, rtol=1e-4, atol=1e-6)
