@@ -21,6 +21,10 @@ from .ops import get_matmul_buffer, matmul                      # noqa: F401
 from .gcn import (gcn, gcn_layer, linear, softmax, softmax_cross_entropy_loss,  # noqa: F401
                   sparse_linear)
 
+from . import dist                                              # noqa: F401
+from .dist import (dist_context, dist_gcn, dist_gcn_layer, dist_row_csr_matrix,  # noqa: F401
+                   dist_row_dn_matrix, dist_row_linear, dist_sparse_linear, repl_dn_matrix)
+
 __all__ = ["context", "csr_matrix", "dn_matrix", "matrix_error", "engine_error", "ops", "matmul",
            "get_matmul_buffer", "sparse_linear", "linear", "gcn_layer", "softmax",
            "softmax_cross_entropy_loss", "gcn", "datasets"]

@@ -144,12 +144,17 @@ def synth_powerlaw_csr(n: int, nnz_target: int, max_deg: int, seed: int = 1, alp
     prep.py:87-94, so columns carry no locality), a self-loop on every row (prep.py:113),
     unit values (the trainer normalises them).  Duplicate columns inside a row are allowed
     (they are legal CSR and every consumer handles them); indices are NOT sorted."""
+    if not (n <= nnz_target <= n * max_deg):
+        raise ValueError(f"cannot place {nnz_target} non-zeros in {n} rows of 1..{max_deg} entries")
     rng = np.random.default_rng(seed)
     # Pareto-like degrees clipped to [1, max_deg], rescaled to hit the nnz target exactly
     raw = (rng.pareto(alpha, size=n) + 1.0)
-    raw = np.minimum(raw, raw.mean() * max_deg / max(nnz_target / n, 1.0))
-    deg = np.maximum(1, np.floor(raw * (nnz_target / raw.sum()))).astype(np.int64)
-    deg = np.minimum(deg, max_deg)
+    w = raw
+    for _ in range(64):          # water-filling: rescale, clip, repeat until the total fits
+        w = np.clip(w * (nnz_target / w.sum()), 1.0, float(max_deg))
+        if abs(w.sum() - nnz_target) < 0.5 * n:
+            break
+    deg = np.clip(np.floor(w), 1, max_deg).astype(np.int64)
     diff = int(nnz_target - deg.sum())
     # distribute the remainder (or remove the surplus) over random rows, one entry each
     while diff != 0:
@@ -182,7 +187,10 @@ def synth_reddit_like(scale: float = 1.0, seed: int = 1):
     ``scale``d-down version with the same mean degree (n multiple of 8 as prep.py:101-103)."""
     n = int(REDDIT_SHAPE["n"] * scale) // 8 * 8
     nnz = int(REDDIT_SHAPE["nnz"] * scale)
-    max_deg = max(8, min(n, int(REDDIT_SHAPE["max_deg"] * min(1.0, scale * 4))))
+    mean_deg = nnz / max(n, 1)
+    # keep the published maximum at full scale; scaled-down graphs keep the skew ratio
+    # (max/mean ~ 44) as far as duplicates-allowed rows make sense
+    max_deg = int(max(4 * mean_deg + 8, REDDIT_SHAPE["max_deg"] * min(1.0, scale * 4)))
     indptr, indices, data = synth_powerlaw_csr(n, nnz, max_deg, seed)
     rng = np.random.default_rng(seed + 1)
     X = rng.standard_normal((n, REDDIT_SHAPE["features"]), dtype=np.float32)

@@ -1,0 +1,566 @@
+"""1D row (vertex) partition of the GCN: one process per GPU over torch.distributed.
+
+Reference: the single-process, P-GPU classes ``dist_context`` (src/dist_matrix.hpp:12-90),
+``dist_row_csr_matrix`` (:170-260), ``dist_row_dn_matrix`` (:394-532), ``repl_dn_matrix``
+(:534-639), ``dist_sparse_linear`` / ``dist_row_linear`` / ``dist_gcn_layer`` /
+``dist_row_softmax_cross_entropy_loss`` / ``dist_gcn`` (src/gcn.hpp:50-86, :191-296,
+:520-637, :872-935, :997-1056) and the pipelined distributed SpMM
+(src/cuda_utils.hpp:57-92).  Same names, same math, same timer names -- but each
+process holds ONLY its own GPU's pieces (rank j owns row block j of A, shard j of
+every activation / gradient, a replica of W): `M[i]` of the reference becomes the
+local `M.local`.  The single-process, all-GPUs-in-one-thread form lives in the C++
+header layer (mg-gcn_amd/host).
+
+Exchange step (the reference broadcasts every shard in P rounds, double-buffered,
+src/cuda_utils.hpp:61-89).  Two modes:
+
+``allgather`` (default, MI355X-first): ONE all-gather of the [n/P x d] shards into a
+    resident [n x d] buffer on the high-priority comm stream -- on the xGMI full mesh
+    every GPU pushes to all 7 peers at once -- while the compute stream already
+    multiplies the local diagonal block A[j,j] (needs no communication); the
+    remaining P-1 blocks are pre-merged at partition time into one CSR with global
+    column indices and run as a single SpMM over the gathered buffer (beta = 1).
+    C_j = A[j,j].B_j + sum_{i!=j} A[j,i].B_i  -- the reference's sum, regrouped.
+``rounds``: the reference's schedule, one broadcast + one block SpMM per round i,
+    double-buffered, accumulating in round order (used for order-exact parity tests
+    and as the `-S`-style baseline).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, ops
+from .gcn import MGGCN_SPMM_LEAKY_RELU, _SQRT_1_3, softmax_cross_entropy_loss
+from .matrix import context, csr_matrix, dn_matrix
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+# --------------------------------------------------------------------------------------
+# host-side partitioning (pure numpy + the C ABI's host functions; no GPU needed)
+# --------------------------------------------------------------------------------------
+def partition_bounds(n: int, P: int) -> List[int]:
+    """p[i] = i*n/P (reference src/main.cpp:139-141); requires n % P == 0
+    (src/dist_matrix.hpp:428; the data prep pads n to a multiple of 8)."""
+    if n % P != 0:
+        raise ValueError(f"n = {n} is not a multiple of the number of GPUs {P}")
+    return [i * n // P for i in range(P + 1)]
+
+
+def split_row_block(A: csr_matrix, row_begin: int, row_end: int, q: Sequence[int]) -> List[csr_matrix]:
+    """Row block [row_begin,row_end) of A cut at the column boundaries q into len(q)-1
+    CSR blocks with block-local column indices: one row of the reference's P x P grid
+    (src/dist_matrix.hpp:215-259)."""
+    lib = _lib.load()
+    qa = np.ascontiguousarray(q, dtype=np.uint32)
+    nq = len(q) - 1
+    rows = row_end - row_begin
+    bip = np.empty((nq, rows + 1), dtype=np.uint32)
+    lib.mggcn_csr_block_split_count_host(A.indptr.ctypes.data, A.indices.ctypes.data, row_begin, row_end,
+                                         qa.ctypes.data, nq, bip.ctypes.data)
+    idx = [np.empty(int(bip[j, rows]), dtype=np.uint32) for j in range(nq)]
+    dat = [np.empty(int(bip[j, rows]), dtype=np.float32) for j in range(nq)]
+    ip = (ctypes.c_void_p * nq)(*[a.ctypes.data for a in idx])
+    dp = (ctypes.c_void_p * nq)(*[a.ctypes.data for a in dat])
+    lib.mggcn_csr_block_split_fill_host(A.indptr.ctypes.data, A.indices.ctypes.data, A.data.ctypes.data,
+                                        row_begin, row_end, qa.ctypes.data, nq, bip.ctypes.data, ip, dp)
+    return [csr_matrix(bip[j].copy(), idx[j], dat[j], int(qa[j + 1] - qa[j])) for j in range(nq)]
+
+
+def split_local_remote(A: csr_matrix, row_begin: int, row_end: int) -> Tuple[csr_matrix, csr_matrix]:
+    """The all-gather form of the same row block: (diagonal block with local column
+    indices, everything else with GLOBAL column indices).  Built with the same block
+    splitter: cut at [0, row_begin, row_end, n] and merge the two outer blocks."""
+    n = A.m()
+    q = [0, row_begin, row_end, n]
+    left, diag, right = split_row_block(A, row_begin, row_end, q)
+    rows = row_end - row_begin
+    ln = np.diff(left.indptr.astype(np.int64))
+    rn = np.diff(right.indptr.astype(np.int64))
+    indptr = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(ln + rn, out=indptr[1:])
+    nnz = int(indptr[-1])
+    indices = np.empty(nnz, dtype=np.uint32)
+    data = np.empty(nnz, dtype=np.float32)
+    # per row: left entries (global index = local) then right entries (+ row_end)
+    lpos = (np.repeat(indptr[:-1], ln) + (np.arange(int(ln.sum())) - np.repeat(left.indptr[:-1].astype(np.int64), ln)))
+    rpos = (np.repeat(indptr[:-1] + ln, rn) + (np.arange(int(rn.sum())) - np.repeat(right.indptr[:-1].astype(np.int64), rn)))
+    indices[lpos] = left.indices
+    data[lpos] = left.data
+    indices[rpos] = right.indices + np.uint32(row_end)
+    data[rpos] = right.data
+    return diag, csr_matrix(indptr.astype(np.uint32), indices, data, n)
+
+
+# --------------------------------------------------------------------------------------
+class dist_context:
+    """reference src/dist_matrix.hpp:12-90, one rank's view.  ``overlap`` selects the
+    comm stream exactly like bcast_stream_id() (:20-22); ``-S`` on the CLI clears it."""
+
+    def __init__(self, overlap: bool = True, device_index: Optional[int] = None, group=None):
+        dist = _dist()
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised (one process per GPU)")
+        self.group = group
+        self.P = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.overlap = overlap
+        self.backend = dist.get_backend(group)
+        if device_index is None:
+            device_index = self.rank % max(_lib.require_gpu(), 1)
+        self.ctx = context(device_index)
+
+    def size(self) -> int: return self.P
+    def bcast_stream_id(self) -> int: return 1 if self.overlap else 0
+    def sync(self) -> None: self.ctx.sync()
+    def record(self, name, stream_id): self.ctx.record(name, stream_id)
+    def wait(self, name, stream_id): self.ctx.wait(name, stream_id)
+    def register_timer(self, name, beg, end): self.ctx.register_timer(name, beg, end)
+    def measure(self, name): return self.ctx.measure(name)
+
+    def dump_timers(self, out, prefix: str = "") -> None:
+        self.ctx.dump_timers(out, f"{prefix}{self.rank}_")      # "<epoch>_<rank>_<name>:ms"
+
+    # -- collectives ------------------------------------------------------------------
+    def _nccl(self) -> bool:
+        return self.backend == "nccl"
+
+    def all_gather_rows(self, shard, out, stream_id: int):
+        """out[rank*rows:(rank+1)*rows] = shard on every rank.  Returns a handle whose
+        .wait(stream_id) orders the result before later work on that stream."""
+        torch, dist = _torch(), _dist()
+        if self._nccl():
+            with torch.cuda.stream(self.ctx.cuda_streams[stream_id]):
+                work = dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True)
+            return _Pending(self, work, None, None)
+        # gloo (CPU rehearsal / several ranks sharing one GPU): stage through the host
+        self.ctx.cuda_streams[stream_id].synchronize()
+        host = shard.detach().cpu().contiguous()
+        parts = [torch.empty_like(host) for _ in range(self.P)]
+        dist.all_gather(parts, host, group=self.group)
+        return _Pending(self, None, torch.cat(parts, dim=0), out)
+
+    def broadcast_rows(self, shard, out, root: int, stream_id: int):
+        torch, dist = _torch(), _dist()
+        src = dist.get_global_rank(self.group, root) if self.group is not None else root
+        if self._nccl():
+            with torch.cuda.stream(self.ctx.cuda_streams[stream_id]):
+                if self.rank == root:
+                    out.copy_(shard)
+                work = dist.broadcast(out, src=src, group=self.group, async_op=True)
+            return _Pending(self, work, None, None)
+        self.ctx.cuda_streams[stream_id].synchronize()
+        host = shard.detach().cpu().contiguous() if self.rank == root else torch.empty(
+            tuple(out.shape), dtype=out.dtype)
+        dist.broadcast(host, src=src, group=self.group)
+        return _Pending(self, None, host, out)
+
+    def all_reduce_sum(self, tensors: Sequence, stream_id: int = 0) -> None:
+        """in-place sum over ranks of several small tensors as ONE flat buffer (the
+        reference all-reduces G_W and G_b separately, src/gcn.hpp:236-240)."""
+        torch, dist = _torch(), _dist()
+        st = self.ctx.cuda_streams[stream_id]
+        with torch.cuda.stream(st):
+            flat = torch.cat([t.reshape(-1) for t in tensors])
+            if self._nccl():
+                dist.all_reduce(flat, group=self.group)
+            else:
+                st.synchronize()
+                host = flat.cpu()
+                dist.all_reduce(host, group=self.group)
+                flat.copy_(host)
+            off = 0
+            for t in tensors:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+
+class _Pending:
+    def __init__(self, dctx, work, host, out):
+        self.dctx, self.work, self.host, self.out = dctx, work, host, out
+
+    def wait(self, stream_id: int) -> None:
+        torch = _torch()
+        with torch.cuda.stream(self.dctx.ctx.cuda_streams[stream_id]):
+            if self.work is not None:
+                self.work.wait()                 # stream-level dependency, host does not block
+            else:
+                self.out.copy_(self.host.to(self.out.device))
+
+
+# --------------------------------------------------------------------------------------
+class dist_row_dn_matrix:
+    """reference src/dist_matrix.hpp:394-532: rows split evenly over the ranks; this
+    process holds shard ``rank`` as ``.local`` ([n/P x m])."""
+
+    def __init__(self, dctx: dist_context, N, M=None, buffer=None, dtype=np.float32):
+        if isinstance(N, np.ndarray):                        # ctor from a host matrix (:440-447)
+            full = N if N.ndim == 2 else N.reshape(-1, 1)
+            p = partition_bounds(full.shape[0], dctx.P)
+            self.N_ = full.shape[0]
+            self.local = dn_matrix.from_numpy(full[p[dctx.rank]:p[dctx.rank + 1]], dctx.ctx.device)
+            return
+        if isinstance(N, tuple):
+            N, M = N
+        if N % dctx.P != 0:
+            raise ValueError("N % P != 0")                   # assert, :428
+        self.N_ = int(N)
+        self.local = dn_matrix(N // dctx.P, M, buffer, dtype, dctx.ctx.device)
+
+    def n(self) -> int: return self.N_
+    def m(self) -> int: return self.local.m()
+    def shape(self): return (self.N_, self.local.m())
+
+
+class repl_dn_matrix:
+    """reference src/dist_matrix.hpp:534-639: a full copy on every rank."""
+
+    def __init__(self, dctx: dist_context, N, M=None):
+        if isinstance(N, tuple):
+            N, M = N
+        self.local = dn_matrix(N, M, device=dctx.ctx.device)
+
+    def n(self): return self.local.n()
+    def m(self): return self.local.m()
+    def shape(self): return self.local.shape()
+
+    def init(self, dctx: dist_context, gain=None) -> None:
+        """reference :601-609 initialises on GPU 0 and broadcasts; every rank running the
+        same seed-99 host generator yields the same bits with no traffic."""
+        self.local.init(gain)
+
+    def zero(self, dctx: dist_context) -> None:
+        self.local.zero(dctx.ctx)
+
+    def allreduce(self, dctx: dist_context) -> None:          # :587-592
+        dctx.all_reduce_sum([self.local.t])
+
+
+class dist_row_csr_matrix:
+    """reference src/dist_matrix.hpp:170-260: A cut into P x P blocks, block (i,j) =
+    rows of rank i x rows-of-H of rank j, block-local column indices.  This process
+    builds only ITS row of blocks, plus the (diagonal, merged-remote) pair used by the
+    all-gather schedule."""
+
+    def __init__(self, dctx: dist_context, A: csr_matrix, p: Sequence[int], q: Sequence[int]):
+        assert list(p) == list(q), "the reference only ever passes p == q (src/main.cpp:148-149)"
+        self.N_, self.M_ = A.n(), A.m()
+        self.p = list(p)
+        r = dctx.rank
+        self.blocks = split_row_block(A, p[r], p[r + 1], q)               # A[{r, j}]
+        self.diag, self.remote = split_local_remote(A, p[r], p[r + 1])
+
+    def n(self): return self.N_
+    def m(self): return self.M_
+    def __getitem__(self, ij): return self.blocks[ij[1]]
+
+
+class dist_sparse_linear:
+    """reference src/gcn.hpp:50-86 + the pipelined matmul src/cuda_utils.hpp:57-92."""
+
+    def __init__(self, name: str, A: dist_row_csr_matrix, A_T: dist_row_csr_matrix, bcast_buffer,
+                 bcast_buffer2, mode: str = "allgather"):
+        self.name, self.A, self.A_T = name, A, A_T
+        self.bcast = [bcast_buffer, bcast_buffer2]
+        self.mode = mode
+        self.plans = {}
+
+    def _plan(self, ctx: context, key, M: csr_matrix, d: int):
+        pl = self.plans.get(key)
+        if pl is None:
+            ctx.set()
+            pl = self.plans[key] = ops.spmm_buffer(
+                ctx.lib, ctx.lib.mggcn_spmm_plan_create(M.n(), M.m(), M.indptr.ctypes.data, max(d, 128)))
+        return pl
+
+    def _run(self, dctx: dist_context, A: dist_row_csr_matrix, tag: str, B: dist_row_dn_matrix,
+             C: dist_row_dn_matrix, discard: bool, flags: int) -> None:
+        torch = _torch()
+        ctx, P, r = dctx.ctx, dctx.P, dctx.rank
+        name = self.name + tag
+        beta = 0.0 if discard else 1.0
+        d = B.m()
+        rows = B.local.n()
+        cs = dctx.bcast_stream_id()
+        ctx.record(name + "0_matmul-spmm", 0)
+        ctx.wait(name + "0_matmul-spmm", 1)                    # comm stream sees the producer of B
+        if self.mode == "allgather":
+            gathered = dn_matrix(rows * P, d, self.bcast[0])
+            ctx.record(name + "0_matmul-bcast-start", cs)
+            pend = dctx.all_gather_rows(B.local.t, gathered.t, cs)
+            # local block first: no dependency on the exchange
+            last_local = flags if P == 1 else 0
+            ops._spmm(ctx, A.diag, B.local, C.local, self._plan(ctx, (tag, "diag"), A.diag, d), 1.0, beta,
+                      last_local)
+            if P > 1:
+                pend.wait(0)
+                ctx.record(name + "0_matmul-bcast-finish", 0)
+                ops._spmm(ctx, A.remote, gathered, C.local, self._plan(ctx, (tag, "remote"), A.remote, d), 1.0,
+                          1.0, flags)
+        else:  # reference schedule: round i = broadcast shard i || SpMM with block (r, i)
+            bufs = [dn_matrix(rows, d, self.bcast[0]), dn_matrix(rows, d, self.bcast[1])]
+            for i in range(P):
+                if i > 1:
+                    ctx.wait(name + f"{i - 1}_matmul-spmm", cs)      # double-buffer hazard (:66-67)
+                ctx.record(name + f"{i}_matmul-bcast-start", cs)
+                pend = dctx.broadcast_rows(B.local.t, bufs[i % 2].t, i, cs)
+                pend.wait(0)
+                ctx.record(name + f"{i}_matmul-bcast-finish", 0)
+                blk = A.blocks[i]
+                ops._spmm(ctx, blk, bufs[i % 2], C.local, self._plan(ctx, (tag, i), blk, d), 1.0,
+                          beta if i == 0 else 1.0, flags if i == P - 1 else 0)
+                ctx.record(name + f"{i + 1}_matmul-spmm", 0)
+        ctx.record(name + "end_matmul-spmm", 0)
+        ctx.register_timer(name + "matmul-spmm", name + "0_matmul-spmm", name + "end_matmul-spmm")
+
+    def __call__(self, dctx, B, C, discard: bool = True, flags: int = 0) -> None:
+        self._run(dctx, self.A, "0_", B, C, discard, flags)
+
+    def backward(self, dctx, G, G_out, discard: bool = True) -> None:
+        self._run(dctx, self.A_T, "1_", G, G_out, discard, 0)
+
+
+class dist_row_linear:
+    """reference src/gcn.hpp:191-296: replicated W/b, row-sharded X; G_b and G_W are
+    summed over ranks (one fused all-reduce instead of the reference's two)."""
+
+    def __init__(self, dctx: dist_context, name: str, in_: int, out: int, backward_out: bool = True,
+                 fused: bool = False):
+        self.name = name
+        self.W, self.G_W = repl_dn_matrix(dctx, in_, out), repl_dn_matrix(dctx, in_, out)
+        self.b, self.G_b = repl_dn_matrix(dctx, 1, out), repl_dn_matrix(dctx, 1, out)
+        self.backward_out, self.fused = backward_out, fused
+        self.W.init(dctx)
+        self.b.init(dctx, _SQRT_1_3)
+        self.X = None
+        self.ones = None
+        self.mW = self.vW = self.mb = self.vb = None
+        self.step = 0
+
+    def setX(self, X): self.X = X
+
+    def __call__(self, dctx: dist_context, X: dist_row_dn_matrix, XW: dist_row_dn_matrix,
+                 discard: bool = True) -> None:
+        ctx, n = dctx.ctx, self.name
+        ops.broadcast_rows(ctx, self.b.local, XW.local, discard)
+        ctx.record(n + "0_0_matmul-gemm", 0)
+        ops.matmul(ctx, X.local, self.W.local, XW.local, 1.0, 1.0)
+        ctx.record(n + "0_1_matmul-gemm", 0)
+        ctx.register_timer(n + "0_matmul-gemm", n + "0_0_matmul-gemm", n + "0_1_matmul-gemm")
+        self.X = X
+
+    def backward(self, dctx: dist_context, G: dist_row_dn_matrix, G_out: Optional[dist_row_dn_matrix],
+                 discard: bool = True) -> None:
+        ctx, n = dctx.ctx, self.name
+        if self.ones is None or self.ones.m() != G.local.n():
+            self.ones = dn_matrix(1, G.local.n(), device=ctx.device)
+            ctx.fill(self.ones, 1.0)
+        ctx.record(n + "1_0_matmul-gemm", 0)
+        ops.matmul(ctx, self.ones, G.local, self.G_b.local, 1.0, 0.0)
+        ops.matmul(ctx, self.X.local, G.local, self.G_W.local, 1.0, 0.0, True)
+        dctx.all_reduce_sum([self.G_W.local.t, self.G_b.local.t])
+        ctx.record(n + "1_2_matmul-gemm", 0)
+        if self.backward_out:
+            ops.matmul(ctx, G.local, self.W.local, G_out.local, 1.0, 0.0 if discard else 1.0, False, True)
+        ctx.record(n + "1_3_matmul-gemm", 0)
+        ctx.register_timer(n + "1_matmul-gemm", n + "1_0_matmul-gemm", n + "1_3_matmul-gemm")
+
+    def adam_update(self, dctx: dist_context, lr, beta1, beta2, weight_decay, eps) -> None:
+        ctx = dctx.ctx
+        if self.mW is None:
+            self.mW, self.vW = repl_dn_matrix(dctx, self.W.shape()), repl_dn_matrix(dctx, self.W.shape())
+            self.mb, self.vb = repl_dn_matrix(dctx, self.b.shape()), repl_dn_matrix(dctx, self.b.shape())
+            for t in (self.mW, self.vW, self.mb, self.vb):
+                t.zero(dctx)
+            self.step = 0
+        self.step += 1
+        bc1 = float(np.float32(1 - beta1 ** self.step))
+        bc2 = float(np.float32(1 - beta2 ** self.step))
+        n = self.name
+        ctx.record(n + "0_adam-update", 0)
+        W, GW, b, Gb = self.W.local, self.G_W.local, self.b.local, self.G_b.local
+        if self.fused:
+            ops.adam_fused(ctx, W, GW, self.mW.local, self.vW.local, lr, beta1, beta2, weight_decay, bc1, bc2, eps)
+            ops.adam_fused(ctx, b, Gb, self.mb.local, self.vb.local, lr, beta1, beta2, 0.0, bc1, bc2, eps)
+        else:
+            ops.axpy(ctx, W, GW, weight_decay)
+            ops.axpby(ctx, GW, self.mW.local, 1 - beta1, beta1)
+            ops.axpby(ctx, Gb, self.mb.local, 1 - beta1, beta1)
+            ops.aaxpby(ctx, GW, self.vW.local, 1 - beta2, beta2)
+            ops.aaxpby(ctx, Gb, self.vb.local, 1 - beta2, beta2)
+            ops.adam_final(ctx, W, self.mW.local, self.vW.local, lr, bc1, bc2, eps)
+            ops.adam_final(ctx, b, self.mb.local, self.vb.local, lr, bc1, bc2, eps)
+        ctx.record(n + "1_adam-update", 0)
+        ctx.register_timer(n + "adam-update", n + "0_adam-update", n + "1_adam-update")
+
+    def get_b(self): return self.b
+    def get_W(self): return self.W
+    def get_G_W(self): return self.G_W
+    def get_G_b(self): return self.G_b
+
+
+class dist_gcn_layer:
+    """reference src/gcn.hpp:520-637 (row_partition = true)."""
+
+    def __init__(self, dctx: dist_context, name: str, A: dist_row_csr_matrix, A_T: dist_row_csr_matrix,
+                 in_: int, out: int, activation: bool, residual_layer: bool = False, backward_spmm: bool = True,
+                 HW_buffer=None, bcast_buffer=None, bcast_buffer2=None, fused: bool = False,
+                 mode: str = "allgather"):
+        torch = _torch()
+        if residual_layer:
+            raise NotImplementedError("residual_layer is never enabled by the reference CLI")
+        P, dev = dctx.P, dctx.ctx.device
+        self.name = name
+        self.A = dist_sparse_linear(name, A, A_T, bcast_buffer, bcast_buffer2, mode)
+        self.lin = dist_row_linear(dctx, name, in_, out, backward_spmm, fused)
+        mn = min(in_, out)
+        self.AHW_buffer = torch.empty(max(A.n() * out, A_T.n() * in_) // P, dtype=torch.float32, device=dev)
+        self.HW = dist_row_dn_matrix(dctx, A.m(), mn, HW_buffer)
+        self.AHW = dist_row_dn_matrix(dctx, A.n(), out, self.AHW_buffer)
+        self.G_HW = dist_row_dn_matrix(dctx, A_T.n(), mn, HW_buffer)
+        self.G_out = dist_row_dn_matrix(dctx, A_T.n(), in_, self.AHW_buffer)
+        self.activation, self.backward_spmm, self.fused = activation, backward_spmm, fused
+        self.H = None
+
+    def __call__(self, dctx: dist_context, H: dist_row_dn_matrix) -> dist_row_dn_matrix:
+        ctx, n = dctx.ctx, self.name
+        self.H = H
+        act_done = False
+        if self.HW.m() == self.AHW.m():
+            self.lin(dctx, H, self.HW)
+            if self.fused and self.activation:
+                self.A(dctx, self.HW, self.AHW, True, MGGCN_SPMM_LEAKY_RELU)
+                act_done = True
+            else:
+                self.A(dctx, self.HW, self.AHW)
+        else:
+            self.A(dctx, H, self.HW)
+            self.lin(dctx, self.HW, self.AHW)
+        if self.activation and not act_done:
+            ctx.record(n + "0_0_activation", 0)
+            ops.leaky_relu_forward(ctx, self.AHW.local, self.AHW.local)
+            ctx.record(n + "0_1_activation", 0)
+            ctx.register_timer(n + "0_activation", n + "0_0_activation", n + "0_1_activation")
+        return self.AHW
+
+    def backward(self, dctx: dist_context, G: dist_row_dn_matrix) -> dist_row_dn_matrix:
+        ctx, n = dctx.ctx, self.name
+        T = G
+        if self.activation:
+            ctx.record(n + "1_0_activation", 0)
+            ops.leaky_relu_backward(ctx, self.AHW.local, G.local, self.AHW.local)
+            ctx.record(n + "1_1_activation", 0)
+            ctx.register_timer(n + "1_activation", n + "1_0_activation", n + "1_1_activation")
+            T = self.AHW
+        if self.HW.m() == self.AHW.m():
+            G_HW = self.G_HW
+            if self.backward_spmm:
+                self.A.backward(dctx, T, G_HW)
+            else:
+                G_HW = T
+            self.lin.backward(dctx, G_HW, self.G_out)
+            return self.G_out
+        self.lin.setX(self.H)
+        self.lin.backward(dctx, T, self.G_HW)
+        if self.backward_spmm:
+            self.A.backward(dctx, self.G_HW, self.G_out)
+            return self.G_out
+        return self.G_HW
+
+    def adam_update(self, dctx, lr, beta1, beta2, weight_decay, eps):
+        self.lin.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
+
+    def b(self): return self.lin.get_b()
+    def W(self): return self.lin.get_W()
+    def GW(self): return self.lin.get_G_W()
+    def Gb(self): return self.lin.get_G_b()
+
+
+class dist_row_softmax_cross_entropy_loss:
+    """reference src/gcn.hpp:872-935: everything is row-local; the gradient is scaled
+    by the GLOBAL n (:908); loss / accuracy are the sums of the per-rank scalars (:929).
+    The reference sums them on the host of its single process; here a 2-float
+    all-reduce does it."""
+
+    def __init__(self, name: str, copy: bool = True, fused: bool = False):
+        self.inner = softmax_cross_entropy_loss(name, copy, fused)
+
+    def __call__(self, dctx: dist_context, H: dist_row_dn_matrix, Y: dist_row_dn_matrix):
+        dist = _dist()
+        self.inner(dctx.ctx, H.local, Y.local, n_global=Y.n(), sync=False)
+        self._G = _wrap_local(self.inner.G, H.n())
+        dctx.sync()                                   # the reference blocks here too (:928)
+        if dctx.backend == "nccl":
+            sums = self.inner.sums.clone()
+            dist.all_reduce(sums, group=dctx.group)
+            sums = sums.cpu()
+        else:
+            sums = self.inner.sums.detach().cpu()
+            dist.all_reduce(sums, group=dctx.group)
+        s = sums.numpy()
+        n = np.float32(H.n())
+        return float(np.float32(s[0]) / n), float(np.float32(s[1]) / n)
+
+    def backward(self) -> dist_row_dn_matrix:
+        return self._G
+
+
+def _wrap_local(dn, n_global):
+    w = dist_row_dn_matrix.__new__(dist_row_dn_matrix)
+    w.N_, w.local = n_global, dn
+    return w
+
+
+class dist_gcn:
+    """reference src/gcn.hpp:997-1056 (row_partition = true): per-GPU HW_buffer and two
+    receive buffers shared by all layers (:1016-1021); layers get (A_T, A) (:1023)."""
+
+    def __init__(self, dctx: dist_context, A: dist_row_csr_matrix, A_T: dist_row_csr_matrix,
+                 sizes: Sequence[int], residual_layer: bool = False, fused: bool = True, mode: str = "allgather"):
+        torch = _torch()
+        P, dev = dctx.P, dctx.ctx.device
+        self.loss_layer = dist_row_softmax_cross_entropy_loss(f"{len(sizes) - 1}_", residual_layer, fused)
+        max_d = max(min(sizes[i], sizes[i + 1]) for i in range(len(sizes) - 1))
+        nmax = max(A.n(), A.m())
+        self.HW_buffer = torch.empty(nmax * max_d // P, dtype=torch.float32, device=dev)
+        # all-gather mode keeps the whole gathered B resident (n x max_d: 119 MB on Reddit,
+        # nothing next to 288 GB); rounds mode needs the reference's two shard-sized buffers
+        big = nmax * max_d if mode == "allgather" else nmax * max_d // P
+        self.bcast_buffer = torch.empty(big, dtype=torch.float32, device=dev)
+        self.bcast_buffer2 = torch.empty(nmax * max_d // P, dtype=torch.float32, device=dev)
+        self.layers_: List[dist_gcn_layer] = []
+        for i in range(1, len(sizes)):
+            self.layers_.append(dist_gcn_layer(dctx, f"{i - 1}_", A_T, A, sizes[i - 1], sizes[i],
+                                               i + 1 < len(sizes), residual_layer, i != 1, self.HW_buffer,
+                                               self.bcast_buffer, self.bcast_buffer2, fused, mode))
+
+    def __call__(self, dctx, H):
+        for layer in self.layers_:
+            H = layer(dctx, H)
+        return H
+
+    def train_forward(self, dctx: dist_context, H: dist_row_dn_matrix, Y: dist_row_dn_matrix):
+        H = self(dctx, H)
+        return self.loss_layer(dctx, H, Y)
+
+    def backward(self, dctx: dist_context) -> None:
+        G = self.loss_layer.backward()
+        for layer in reversed(self.layers_):
+            G = layer.backward(dctx, G)
+
+    def adam_update(self, dctx, lr, beta1, beta2, weight_decay, eps) -> None:
+        for layer in self.layers_:
+            layer.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
+
+    def layers(self): return self.layers_

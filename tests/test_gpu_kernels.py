@@ -1,0 +1,256 @@
+"""Parity of every HIP kernel behind the C ABI against the CPU oracle (the -m gpu
+tests proper).  Floating-point bar: 1e-4 relative (BASELINE.json north_star), measured
+as max|got - want| / max|want| per output and, for the SpMM, additionally row by row
+against the fp64-accumulated oracle so that a wrong row cannot hide behind a large one.
+Integer outputs (argmax, is_equal) are bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def relerr(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+
+
+def rowwise_relerr(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    den = np.abs(want).max(axis=1) + 1e-30
+    return float((np.abs(got - want).max(axis=1) / den).max())
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    return pkg.context(0)
+
+
+def _csr(pkg, oracle, ip, ix, dv, m):
+    return pkg.csr_matrix(ip, ix, dv, m), oracle.Csr(ip, ix, dv, m)
+
+
+def _run_spmm(pkg, ctx, A, B, C0, alpha, beta, flags=0, plan=True, max_d=None):
+    Bd = pkg.dn_matrix.from_numpy(B)
+    Cd = pkg.dn_matrix.from_numpy(C0)
+    buf = pkg.get_matmul_buffer(ctx, A, Bd, Cd, alpha, beta, max_d=max_d) if plan else None
+    pkg.matmul(ctx, A, Bd, Cd, buf, alpha, beta, flags)
+    ctx.sync()
+    return Cd.numpy(), buf
+
+
+@pytest.mark.parametrize("d", [1, 4, 32, 41, 48, 64, 100, 128, 132, 256, 608])
+@pytest.mark.parametrize("plan", [True, False])
+def test_spmm_widths(pkg, oracle, ctx, d, plan):
+    n = 1500
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 60_000, 4000, seed=d)
+    dv = np.random.default_rng(d).random(dv.shape[0], dtype=np.float32)
+    A, Ao = _csr(pkg, oracle, ip, ix, dv, n)
+    rng = np.random.default_rng(d + 1)
+    B = rng.standard_normal((n, d), dtype=np.float32)
+    C0 = rng.standard_normal((n, d), dtype=np.float32)
+    for alpha, beta in [(1.0, 0.0), (0.5, 2.0), (1.0, 1.0)]:
+        got, buf = _run_spmm(pkg, ctx, A, B, C0, alpha, beta, plan=plan)
+        want = oracle.spmm(Ao, B, C0.copy(), alpha, beta, f64acc=True)
+        assert rowwise_relerr(got, want) <= TOL, (d, alpha, beta)
+        if plan:
+            assert buf.num_split_rows() > 0       # max degree 4000 > split threshold: slices exercised
+
+
+def test_spmm_baseline_config_c1(pkg, oracle, ctx):
+    """BASELINE.json configs[0]: 10k nodes / 100k nnz, d = 128, column-normalised values."""
+    n = 10_000
+    ip, ix, dv = pkg.datasets.synth_uniform_csr(n, 10, seed=0)
+    A, Ao = _csr(pkg, oracle, ip, ix, dv, n)
+    A.normalize(True); oracle.normalize(Ao, True)
+    np.testing.assert_array_equal(A.data, Ao.data)
+    B = np.random.default_rng(0).standard_normal((n, 128), dtype=np.float32)
+    got, _ = _run_spmm(pkg, ctx, A, B, np.zeros((n, 128), np.float32), 1.0, 0.0)
+    assert rowwise_relerr(got, oracle.spmm(Ao, B, f64acc=True)) <= TOL
+    assert relerr(got, oracle.spmm(Ao, B)) <= TOL                     # and vs the fp32 restatement
+
+
+def test_spmm_edge_cases(pkg, oracle, ctx):
+    # empty rows, a row longer than one 64-chunk, a row exactly 64 long, duplicates,
+    # beta = 0 over NaN-filled C (never read), rectangular A
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 63, 64, 65, 0, 128, 129, 700, 2, 0]
+    ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    m = 37
+    ix = rng.integers(0, m, size=int(ip[-1]), dtype=np.uint32)
+    dv = rng.standard_normal(int(ip[-1])).astype(np.float32)
+    A, Ao = _csr(pkg, oracle, ip, ix, dv, m)
+    for d in (128, 41, 8):
+        B = rng.standard_normal((m, d)).astype(np.float32)
+        C0 = np.full((len(lens), d), np.nan, dtype=np.float32)
+        for plan in (True, False):
+            got, _ = _run_spmm(pkg, ctx, A, B, C0, 1.0, 0.0, plan=plan)
+            want = oracle.spmm(Ao, B, f64acc=True)
+            assert np.isfinite(got).all()
+            assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+            assert (got[[0, 5, 10]] == 0).all()
+    # zero-row matrix: a no-op, not a crash
+    E = pkg.csr_matrix([0], [], [], 5)
+    pkg.matmul(ctx, E, pkg.dn_matrix.from_numpy(np.ones((5, 4), np.float32)), pkg.dn_matrix(0, 4), None, 1.0, 0.0)
+    ctx.sync()
+
+
+def test_spmm_fused_leaky_relu_and_linearity(pkg, oracle, ctx):
+    n, d = 3000, 128
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 150_000, 2500, seed=9)
+    A, Ao = _csr(pkg, oracle, ip, ix, dv, n)
+    A.normalize(True); oracle.normalize(Ao, True)
+    rng = np.random.default_rng(10)
+    B1 = rng.standard_normal((n, d), dtype=np.float32)
+    B2 = rng.standard_normal((n, d), dtype=np.float32)
+    z = np.zeros((n, d), np.float32)
+    got, _ = _run_spmm(pkg, ctx, A, B1, z, 1.0, 0.0, flags=1)
+    want = oracle.leaky_relu_forward(oracle.spmm(Ao, B1))
+    assert relerr(got, want) <= TOL
+    # size-independent property: A(B1 + 2 B2) == A B1 + 2 A B2
+    s, _ = _run_spmm(pkg, ctx, A, B1 + 2 * B2, z, 1.0, 0.0)
+    a, _ = _run_spmm(pkg, ctx, A, B1, z, 1.0, 0.0)
+    b, _ = _run_spmm(pkg, ctx, A, B2, z, 1.0, 0.0)
+    assert relerr(s, a + 2 * b) <= TOL
+    # row-stochastic matrix times ones == ones  (checksum of the normalisation + kernel)
+    At = A.transpose()
+    o, _ = _run_spmm(pkg, ctx, At, np.ones((n, d), np.float32), z, 1.0, 0.0)
+    np.testing.assert_allclose(o, 1.0, rtol=1e-5)
+
+
+def test_spmm_is_bitwise_reproducible(pkg, ctx):
+    n, d = 4000, 128
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 300_000, 5000, seed=2)
+    A = pkg.csr_matrix(ip, ix, dv, n)
+    B = np.random.default_rng(3).standard_normal((n, d), dtype=np.float32)
+    z = np.zeros((n, d), np.float32)
+    a, _ = _run_spmm(pkg, ctx, A, B, z, 1.0, 0.0)
+    b, _ = _run_spmm(pkg, ctx, A, B, z, 1.0, 0.0)
+    np.testing.assert_array_equal(a, b)          # split rows are combined in a fixed order
+
+
+GEMM_SHAPES = [  # (M, N, K, A_T, B_T)
+    (300, 128, 608, False, False),      # H.W   (first layer)
+    (300, 41, 128, False, False),       # logits layer, N not a multiple of 4
+    (257, 128, 128, False, True),       # G.W^T
+    (608, 128, 5000, True, False),      # G_W = X^T G, split-K
+    (128, 41, 3001, True, False),       # split-K with ragged K and narrow N
+    (1, 128, 4097, False, False),       # G_b = ones . G
+    (700, 1, 41, False, False),         # softmax row sums (GEMM with a ones vector)
+    (2, 2, 3, False, False), (2, 3, 2, True, False), (129, 65, 33, True, True),
+]
+
+
+@pytest.mark.parametrize("M,N,K,A_T,B_T", GEMM_SHAPES)
+def test_gemm(pkg, oracle, ctx, M, N, K, A_T, B_T):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((K, M) if A_T else (M, K)).astype(np.float32)
+    B = rng.standard_normal((N, K) if B_T else (K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    for alpha, beta in [(1.0, 0.0), (1.0, 1.0), (-0.5, 0.25)]:
+        Ad, Bd, Cd = (pkg.dn_matrix.from_numpy(x) for x in (A, B, C0))
+        pkg.matmul(ctx, Ad, Bd, Cd, alpha, beta, A_T, B_T)
+        ctx.sync()
+        want = oracle.gemm(A, B, C0.copy(), alpha, beta, A_T, B_T, f64acc=True)
+        assert relerr(Cd.numpy(), want) <= TOL, (alpha, beta)
+
+
+def test_gemm_beta_zero_ignores_nan_and_shape_errors(pkg, ctx):
+    A = pkg.dn_matrix.from_numpy(np.ones((5, 7), np.float32))
+    B = pkg.dn_matrix.from_numpy(np.ones((7, 3), np.float32))
+    C = pkg.dn_matrix.from_numpy(np.full((5, 3), np.nan, np.float32))
+    pkg.matmul(ctx, A, B, C, 1.0, 0.0)
+    ctx.sync()
+    np.testing.assert_array_equal(C.numpy(), 7.0)
+    with pytest.raises(ValueError):
+        pkg.matmul(ctx, A, A, C, 1.0, 0.0)
+
+
+def test_elementwise_kernels(pkg, oracle, ctx):
+    ops = pkg.ops
+    rng = np.random.default_rng(0)
+    for shape in [(1000, 128), (333, 41), (7, 3)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        g = rng.standard_normal(shape).astype(np.float32)
+        X, Gm = pkg.dn_matrix.from_numpy(x), pkg.dn_matrix.from_numpy(g)
+        out = pkg.dn_matrix(shape)
+        ops.leaky_relu_forward(ctx, X, out); ctx.sync()
+        np.testing.assert_array_equal(out.numpy(), oracle.leaky_relu_forward(x))
+        ops.leaky_relu_backward(ctx, X, Gm, out); ctx.sync()
+        np.testing.assert_array_equal(out.numpy(), oracle.leaky_relu_backward(x, g))
+        ops.leaky_relu_forward(ctx, X, X); ctx.sync()                      # in place (gcn.hpp:449)
+        np.testing.assert_array_equal(X.numpy(), oracle.leaky_relu_forward(x))
+        # broadcast_rows: discard and accumulate
+        row = rng.standard_normal((1, shape[1])).astype(np.float32)
+        R, M = pkg.dn_matrix.from_numpy(row), pkg.dn_matrix.from_numpy(x)
+        ops.broadcast_rows(ctx, R, M, False); ctx.sync()
+        np.testing.assert_array_equal(M.numpy(), x + row)
+        ops.broadcast_rows(ctx, R, M, True); ctx.sync()
+        np.testing.assert_array_equal(M.numpy(), np.broadcast_to(row, shape))
+        # axpy / axpby / aaxpby / scale_mat
+        Bm = pkg.dn_matrix.from_numpy(g)
+        ops.axpby(ctx, pkg.dn_matrix.from_numpy(x), Bm, 0.1, 0.9); ctx.sync()
+        np.testing.assert_allclose(Bm.numpy(), np.float32(0.1) * x + np.float32(0.9) * g, rtol=1e-6, atol=1e-7)
+        Bm = pkg.dn_matrix.from_numpy(g)
+        ops.aaxpby(ctx, pkg.dn_matrix.from_numpy(x), Bm, 0.001, 0.999); ctx.sync()
+        np.testing.assert_allclose(Bm.numpy(), np.float32(0.001) * x * x + np.float32(0.999) * g, rtol=1e-6, atol=1e-7)
+        Bm = pkg.dn_matrix.from_numpy(g)
+        ops.axpy(ctx, pkg.dn_matrix.from_numpy(x), Bm, 5e-4); ctx.sync()
+        np.testing.assert_allclose(Bm.numpy(), g + np.float32(5e-4) * x, rtol=1e-6, atol=1e-7)
+        ops.scale_mat(ctx, Bm, 0.25); ctx.sync()
+        np.testing.assert_allclose(Bm.numpy(), (g + np.float32(5e-4) * x) * np.float32(0.25), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,m", [(5000, 41), (1000, 48), (300, 128), (64, 3), (10, 300)])
+def test_loss_chain_and_fused_loss(pkg, oracle, ctx, n, m):
+    import torch
+    rng = np.random.default_rng(n + m)
+    H = (rng.standard_normal((n, m)) * 3).astype(np.float32)
+    H[0, :] = 1.5                                           # full tie: first index must win
+    if m > 2:
+        H[1, [1, 2]] = H[1].max() + 1                       # two-way tie
+    Y = rng.integers(0, m, size=(n, 1)).astype(np.int32)
+    ls, ac, G, O = oracle.softmax_cross_entropy(H, Y, n_global=2 * n)
+    for fused in (False, True):
+        L = pkg.softmax_cross_entropy_loss("t_", copy=True, fused=fused)
+        Hd, Yd = pkg.dn_matrix.from_numpy(H), pkg.dn_matrix.from_numpy(Y)
+        loss, acc = L(ctx, Hd, Yd, n_global=2 * n)
+        assert abs(loss * n - ls) <= 1e-4 * abs(ls), fused
+        assert round(acc * n) == round(ac), fused                     # integer-exact
+        assert relerr(L.backward().numpy(), G) <= TOL, fused
+        np.testing.assert_array_equal(Hd.numpy(), H)                   # copy=True leaves the logits alone
+    # the unfused chain's intermediate kernels, bit-exact where integer
+    Hd = pkg.dn_matrix.from_numpy(H)
+    P = pkg.dn_matrix(n, 1, dtype=np.int32)
+    pkg.ops.max_row_indices(ctx, Hd, P); ctx.sync()
+    np.testing.assert_array_equal(P.numpy().reshape(-1), H.argmax(axis=1))
+    mx = pkg.dn_matrix(n, 1)
+    pkg.ops.max_rows(ctx, Hd, mx); ctx.sync()
+    np.testing.assert_array_equal(mx.numpy().reshape(-1), H.max(axis=1))
+    T = pkg.dn_matrix(n, 1)
+    pkg.ops.is_equal(ctx, pkg.dn_matrix.from_numpy(Y), P, T); ctx.sync()
+    np.testing.assert_array_equal(T.numpy().reshape(-1), (Y.reshape(-1) == H.argmax(axis=1)).astype(np.float32))
+    s = torch.empty(1, dtype=torch.float32, device="cuda")
+    pkg.ops.abssum(ctx, Hd, s); ctx.sync()
+    assert abs(float(s.item()) - np.abs(H.astype(np.float64)).sum()) <= 1e-5 * np.abs(H).sum()
+
+
+def test_adam_fused_equals_chain_equals_oracle(pkg, oracle, ctx):
+    for fused in (False, True):
+        lin = pkg.linear("0_", 64, 32, True, fused)
+        ol = oracle.Linear(64, 32)
+        np.testing.assert_array_equal(lin.W.numpy(), ol.W)              # same seed-99 init
+        np.testing.assert_array_equal(lin.b.numpy(), ol.b)
+        rng = np.random.default_rng(1)
+        for step in range(3):
+            gw = rng.standard_normal((64, 32)).astype(np.float32)
+            gb = rng.standard_normal((1, 32)).astype(np.float32)
+            lin.G_W.init(gw); lin.G_b.init(gb)
+            ol.G_W, ol.G_b = gw.copy(), gb.copy()
+            lin.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8); ctx.sync()
+            ol.adam_update(1e-2, 0.9, 0.999, 5e-4, 1e-8)
+            assert relerr(lin.W.numpy(), ol.W) <= 1e-5
+            assert relerr(lin.b.numpy(), ol.b) <= 1e-5
