@@ -88,21 +88,29 @@ void mggcn_memset_zero(void *dst, size_t bytes, mggcn_stream_t stream);
  * workspace query get_matmul_buffer (src/cuda_utils.hpp:94-102).
  * ======================================================================== */
 
-/* The "external buffer" of the reference becomes a plan: row-split metadata that
- * load-balances heavy-tailed degree distributions (rows longer than the split
- * threshold are cut into several work items whose partial sums are combined in a
- * fixed order -> bitwise reproducible) plus the partial-sum workspace for feature
- * widths up to max_d.  Built once per matrix from the HOST copy of indptr; holds
- * only device memory it allocated itself.  The matrix arrays passed to
- * mggcn_spmm_csr_f32 with a plan must be the ones the plan was built for. */
+/* The "external buffer" of the reference becomes a plan, built once per matrix from
+ * the HOST copy of the CSR arrays; it holds only device memory it allocated itself:
+ *  - row-split metadata that load-balances heavy-tailed degree distributions (rows
+ *    longer than the split threshold are cut into work items whose partial sums are
+ *    combined in a fixed order -> bitwise reproducible) and the partial-sum workspace
+ *    for feature widths up to max_d;
+ *  - when host_indices / host_values are given and the matrix is large (>= 2^20
+ *    non-zeros), the column-panel "sweep" form: the non-zeros re-cut into equal-work
+ *    per-wave streams sorted by column panel, so that every wave on the chip walks B
+ *    in the same order and the active panel stays L2-resident (a private device copy
+ *    of the matrix, 8 B per non-zero).  Pass NULL for both to skip it.
+ * The arrays later passed to mggcn_spmm_csr_f32 with a plan must hold the matrix the
+ * plan was built for (the sweep form reads its own copy). */
 typedef struct mggcn_spmm_plan mggcn_spmm_plan;
 
 mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,
-                                        const uint32_t *host_indptr, uint32_t max_d);
+                                        const uint32_t *host_indptr, const uint32_t *host_indices,
+                                        const float *host_values, uint32_t max_d);
 void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan);
 /* introspection (tests, DESIGN.md figures) */
 uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan);
 uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan);
+uint32_t mggcn_spmm_plan_num_sweep_tasks(const mggcn_spmm_plan *plan); /* 0: no sweep form */
 size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan);
 
 /* flags */

@@ -46,10 +46,11 @@ PROTOTYPES = {
     "mggcn_memcpy_d2h": (None, [vp, vp, c_size_t, vp]),
     "mggcn_memcpy_d2d": (None, [vp, vp, c_size_t, vp]),
     "mggcn_memset_zero": (None, [vp, c_size_t, vp]),
-    "mggcn_spmm_plan_create": (vp, [c_uint32, c_uint32, vp, c_uint32]),
+    "mggcn_spmm_plan_create": (vp, [c_uint32, c_uint32, vp, vp, vp, c_uint32]),
     "mggcn_spmm_plan_destroy": (None, [vp]),
     "mggcn_spmm_plan_num_items": (c_uint32, [vp]),
     "mggcn_spmm_plan_num_split_rows": (c_uint32, [vp]),
+    "mggcn_spmm_plan_num_sweep_tasks": (c_uint32, [vp]),
     "mggcn_spmm_plan_bytes": (c_size_t, [vp]),
     "mggcn_spmm_csr_f32": (None, [vp, vp, c_uint32, c_uint32, vp, vp, vp, vp, c_size_t, vp, c_size_t,
                                   c_uint32, c_float, c_float, c_uint32, c_float]),

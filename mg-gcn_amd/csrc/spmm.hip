@@ -26,9 +26,11 @@
 //    epilogue; beta == 0 never reads C.
 #include <algorithm>
 #include <numeric>
+#include <string>
 #include <vector>
 
 #include "common.h"
+#include "spmm_internal.h"
 
 namespace {
 
@@ -256,10 +258,13 @@ struct mggcn_spmm_plan {
     float *d_partial = nullptr;
     size_t bytes = 0;
     int device = 0;
+    SweepPlan *sweep = nullptr;     // column-panel sweep form (large matrices; spmm_sweep.hip)
 };
 
 MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,
-                                                  const uint32_t *host_indptr, uint32_t max_d) {
+                                                  const uint32_t *host_indptr,
+                                                  const uint32_t *host_indices,
+                                                  const float *host_values, uint32_t max_d) {
     MGGCN_REQUIRE(host_indptr != nullptr || n_rows == 0, "plan needs the host copy of indptr");
     MGGCN_REQUIRE(max_d > 0, "max_d must be positive");
     // slice length for heavy rows; rows up to 1.5x the slice stay whole
@@ -308,11 +313,15 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_co
     }
     if (pb) MGGCN_CHECK_HIP(hipMalloc(&plan->d_partial, pb));
     plan->bytes = ib + sb + pb;
+    const char *algo = std::getenv("MGGCN_SPMM_ALGO");
+    if (host_indices && host_values && !(algo && std::string(algo) == "rowsplit"))
+        plan->sweep = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d);
     return plan;
 }
 
 MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {
     if (!plan) return;
+    sweep_plan_destroy(plan->sweep);
     if (plan->d_items) MGGCN_CHECK_HIP(hipFree(plan->d_items));
     if (plan->d_split) MGGCN_CHECK_HIP(hipFree(plan->d_split));
     if (plan->d_partial) MGGCN_CHECK_HIP(hipFree(plan->d_partial));
@@ -321,7 +330,12 @@ MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {
 
 MGGCN_API uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan) { return plan->n_items; }
 MGGCN_API uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan) { return plan->n_split_rows; }
-MGGCN_API size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan) { return plan->bytes; }
+MGGCN_API size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan) {
+    return plan->bytes + sweep_plan_bytes(plan->sweep);
+}
+MGGCN_API uint32_t mggcn_spmm_plan_num_sweep_tasks(const mggcn_spmm_plan *plan) {
+    return sweep_plan_tasks(plan->sweep);
+}
 
 namespace {
 
@@ -370,6 +384,10 @@ MGGCN_API void mggcn_spmm_csr_f32(mggcn_stream_t stream, const mggcn_spmm_plan *
     if (plan) {
         MGGCN_REQUIRE(plan->n_rows == n_rows && plan->n_cols == n_cols, "plan built for another matrix");
         MGGCN_REQUIRE(d <= plan->max_d || plan->n_slots == 0, "feature width exceeds the plan's max_d");
+        if (plan->sweep && sweep_supports(plan->sweep, d, ldb, ldc, B, C)) {
+            sweep_launch(st, plan->sweep, B, ldb, C, ldc, d, alpha, beta, flags, slope);
+            return;
+        }
         launch_main<true>(st, plan, plan->n_items, indptr, indices, values, B, ldb, C, ldc, d, alpha,
                           beta, flags, slope);
         if (plan->n_split_rows) {

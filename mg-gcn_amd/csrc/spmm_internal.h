@@ -1,0 +1,20 @@
+// spmm_internal.h -- shared between spmm.hip (C ABI + row-split kernels) and
+// spmm_sweep.hip (column-panel sweep kernels).  Not part of the ABI.
+#pragma once
+
+#include "common.h"
+
+struct SweepPlan;   // opaque to spmm.hip
+
+// Builds the panel-swept entry stream for one CSR matrix (host arrays) and uploads it.
+// Returns nullptr when the matrix is not worth sweeping (tiny).
+SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
+                            const uint32_t *indices, const float *values, uint32_t max_d);
+void sweep_plan_destroy(SweepPlan *p);
+size_t sweep_plan_bytes(const SweepPlan *p);
+uint32_t sweep_plan_tasks(const SweepPlan *p);
+uint32_t sweep_plan_split_rows(const SweepPlan *p);
+// true if this (d, alignment) combination is served by the sweep kernels
+bool sweep_supports(const SweepPlan *p, uint32_t d, size_t ldb, size_t ldc, const void *B, const void *C);
+void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb, float *C, size_t ldc,
+                  uint32_t d, float alpha, float beta, uint32_t flags, float slope);

@@ -1,0 +1,481 @@
+// spmm_sweep.hip -- column-panel "sweep" SpMM for gfx950: the L2-resident gather.
+//
+// Why: the row-per-wave kernel (spmm.hip) already runs at the Infinity-Cache gather
+// rate (8.7 TB/s of 512-B row fetches on the Reddit shape, rocprof r01: 50 GB leave
+// the XCD L2s per launch against 1.16 GB of algorithmic bytes, L2 hit rate 17 %).
+// The same kernel with every column index confined to a 2 MiB window of B runs 2.9x
+// faster (22 TB/s, profiles/experiments/l2_window.py).  B as a whole (119 MB) cannot
+// live in a 4 MiB L2 -- but a PANEL of it can, if every wave on the chip walks the
+// columns in the same order at the same pace.
+//
+// How: at plan time the matrix is re-cut into equal-work tasks, one per wave64:
+//   * a task owns <= RW output rows (heavy rows are first cut into slices, as in the
+//     row-split plan; slices get partial-sum slots combined in a fixed order);
+//   * tasks are balanced by non-zero count (longest-processing-time greedy), so every
+//     wave has the same amount of work;
+//   * a task's non-zeros are stored as ONE stream sorted by (column panel, row): the
+//     wave sweeps the column space panel by panel.  Entry = 8 bytes:
+//     {run_start:1 | row_local:4 | column:27, value}.
+//   * the wave keeps its RW accumulator rows in LDS (RW x 512 B = 8 KiB); runs of
+//     entries with the same row are summed in registers and folded into LDS at the
+//     run boundary (wave-private rows -> plain read-modify-write, no atomics, fixed
+//     order -> bitwise reproducible).
+// Because all resident waves start together (one launch per "round" of resident
+// tasks), have equal work and see the same column distribution, they cross each
+// panel at about the same time: the panel is pulled from the Infinity Cache once per
+// XCD and then hit in L2 by ~600 waves.  Placement is a speed matter only; results
+// never depend on it.
+#include <algorithm>
+#include <cstring>
+#include <queue>
+#include <thread>
+#include <vector>
+
+#include "spmm_internal.h"
+
+// (hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b64/_b128 lower to a single dword load
+// splatted over the result -- checked in the IR -- so the LLVM intrinsics are bound directly.)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ f32x2_t mggcn_buffer_load_v2f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v2f32");
+__device__ float mggcn_buffer_load_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.f32");
+
+namespace {
+
+constexpr int kRW = 16;                 // output rows per wave (5 bits available)
+constexpr uint32_t kColBits = 27;       // columns < 134 M (papers100M: 111 M)
+constexpr uint32_t kColMask = (1u << kColBits) - 1;
+constexpr uint32_t kSlotFlag = 0x80000000u;
+constexpr uint32_t kRunFlag = 0x80000000u;     // entry bit 31: first entry of a (panel,row) run; bits 30..27: row
+constexpr int kWavesPerBlock = 4;
+
+struct SweepTask {
+    uint32_t beg, end;   // entry range
+    uint32_t n_rows;     // rows in use (<= kRW)
+    uint32_t pad;
+};
+
+struct SweepSplitRow {
+    uint32_t row, first_slot, n_slots, pad;
+};
+
+__device__ __forceinline__ float lrelu(float x, float slope) {
+    const float y = slope * x;
+    return x > y ? x : y;
+}
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> {
+    float v;
+    __device__ __forceinline__ void zero() { v = 0.f; }
+    __device__ __forceinline__ void fma(float s, const Vec &b) { v = fmaf(s, b.v, v); }
+    __device__ __forceinline__ void add(const Vec &b) { v += b.v; }
+    __device__ __forceinline__ static Vec load(const float *p) { Vec r; r.v = *p; return r; }
+    __device__ __forceinline__ void store(float *p) const { *p = v; }
+    template <typename F> __device__ __forceinline__ void map(const float *c, F f) { v = f(v, c[0]); }
+};
+template <> struct Vec<2> {
+    float2 v;
+    __device__ __forceinline__ void zero() { v = make_float2(0.f, 0.f); }
+    __device__ __forceinline__ void fma(float s, const Vec &b) { v.x = fmaf(s, b.v.x, v.x); v.y = fmaf(s, b.v.y, v.y); }
+    __device__ __forceinline__ void add(const Vec &b) { v.x += b.v.x; v.y += b.v.y; }
+    __device__ __forceinline__ static Vec load(const float *p) { Vec r; r.v = *reinterpret_cast<const float2 *>(p); return r; }
+    __device__ __forceinline__ void store(float *p) const { *reinterpret_cast<float2 *>(p) = v; }
+    template <typename F> __device__ __forceinline__ void map(const float *c, F f) { v.x = f(v.x, c[0]); v.y = f(v.y, c[1]); }
+};
+
+// Entry batches are 8 entries = 64 bytes, 64-byte aligned (the plan pads every task's
+// stream to a multiple of 8 with zero-valued entries), so one s_load_dwordx16 brings a
+// batch straight into scalar registers: no VGPRs, no cross-lane broadcast, and -- because
+// scalar loads count on lgkmcnt, not vmcnt -- the HBM-latency entry stream never sits in
+// front of the L2-latency row gathers in the in-order vector-memory queue.
+struct EntryBatch {
+    uint4 q[4];
+    __device__ __forceinline__ uint32_t pk(int u) const {
+        const uint4 &x = q[u >> 1];
+        return (u & 1) ? x.z : x.x;
+    }
+    __device__ __forceinline__ float val(int u) const {
+        const uint4 &x = q[u >> 1];
+        return __builtin_bit_cast(float, (u & 1) ? x.w : x.y);
+    }
+};
+
+__device__ __forceinline__ EntryBatch load_batch(const uint2 *__restrict__ entries, uint32_t e) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(entries + e);   // wave-uniform address
+    EntryBatch r;
+    r.q[0] = p[0]; r.q[1] = p[1]; r.q[2] = p[2]; r.q[3] = p[3];
+    return r;
+}
+
+// The wave's RW = 16 accumulator rows live in REGISTERS: one 16-wide vector register
+// group per feature plane (plane k, element r = feature k of row r for this lane).  A run
+// of entries with the same row is summed in `acc`; at the run boundary `acc` is added to
+// element `row` of each plane.  `row` is wave-uniform, so the compiler indexes the VGPR
+// group through the gfx9 index mode (s_set_gpr_idx_on): two moves per plane, no branch
+// tree, no LDS, no memory wait on the fold.  (Measured alternatives: LDS float atomics
+// serialise per lane, ~150 cycles per ds_add_f32 wave op; LDS read-modify-write puts an
+// lgkmcnt wait on every run boundary.)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// NOTE: the planes must be separate LOCAL vector variables.  Wrapped in a struct (or an
+// array of vectors) the compiler keeps them in scratch memory (192 B) instead of using the
+// index mode -- checked in the ISA.
+#define MGGCN_ROWS_GET(R) (VEC == 2 ? make_float2(p0[R], p1[R]) : make_float2(p0[R], 0.f))
+
+template <int VEC> __device__ __forceinline__ Vec<VEC> vec_from2(float2 x);
+template <> __device__ __forceinline__ Vec<1> vec_from2<1>(float2 x) { Vec<1> r; r.v = x.x; return r; }
+template <> __device__ __forceinline__ Vec<2> vec_from2<2>(float2 x) { Vec<2> r; r.v = x; return r; }
+template <int VEC> __device__ __forceinline__ float2 vec_to2(const Vec<VEC> &v);
+template <> __device__ __forceinline__ float2 vec_to2<1>(const Vec<1> &v) { return make_float2(v.v, 0.f); }
+template <> __device__ __forceinline__ float2 vec_to2<2>(const Vec<2> &v) { return v.v; }
+
+// Row gathers go through a buffer descriptor over B: the per-entry address is then ONE
+// scalar multiply (column * row bytes -> soffset) and no vector ALU work at all
+// (buffer_load_dwordx2 v, v_lane_offset, s[rsrc], s_row_offset offen).  The kernel is
+// otherwise bound by scalar-instruction issue, not by memory (rocprof r01: 13 SALU
+// instructions per non-zero in the first version).
+template <int VEC> struct BufLoad;
+template <> struct BufLoad<1> {
+    __device__ __forceinline__ static Vec<1> load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+        Vec<1> r;
+        r.v = mggcn_buffer_load_f32(rsrc, (int)voff, (int)soff, 0);
+        return r;
+    }
+};
+template <> struct BufLoad<2> {
+    __device__ __forceinline__ static Vec<2> load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+        const f32x2_t x = mggcn_buffer_load_v2f32(rsrc, (int)voff, (int)soff, 0);
+        Vec<2> r;
+        r.v = make_float2(x[0], x[1]);
+        return r;
+    }
+};
+
+template <int VEC>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_kernel(
+    const SweepTask *__restrict__ tasks, uint32_t task0, uint32_t n_launch,
+    const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
+    const float *__restrict__ B, uint32_t b_bytes, uint32_t row_bytes, float *__restrict__ C, size_t ldc,
+    float *__restrict__ partial, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    static_assert(kRW == 16, "the accumulator planes hold 16 rows");
+    constexpr int TILE = 64 * VEC;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wib = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
+    const uint32_t local = blockIdx.x * kWavesPerBlock + wib;
+    if (local >= n_launch) return;                    // no barriers: waves are independent
+    const uint32_t t = task0 + local;
+    const SweepTask task = tasks[t];
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, b_bytes, 0x00020000);
+
+    for (uint32_t col0 = 0; col0 < d; col0 += TILE) {
+        const uint32_t col = col0 + lane * VEC;
+        const bool active = col < d;                  // VEC == 2 is only used with even d
+        const uint32_t lane_off = (active ? col : 0) * 4u;   // idle lanes re-read column 0 (never stored)
+        f32x16 p0, p1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { p0[r] = 0.f; p1[r] = 0.f; }
+        uint32_t cur_row = 0;                         // row 0 is a valid sink for an empty prefix
+        Vec<VEC> acc; acc.zero();
+
+        if (task.beg < task.end) {
+            EntryBatch cur = load_batch(entries, task.beg);
+            for (uint32_t e = task.beg; e < task.end; e += 8) {
+                const uint32_t e_next = e + 8 < task.end ? e + 8 : e;     // last batch re-reads itself
+                const EntryBatch nxt = load_batch(entries, e_next);
+                Vec<VEC> b[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    b[u] = BufLoad<VEC>::load(rsrc, lane_off, (cur.pk(u) & kColMask) * row_bytes);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t pk = cur.pk(u);
+                    if (pk & kRunFlag) {                                   // first entry of a (panel,row) run
+                        const float2 a2 = vec_to2<VEC>(acc);
+                        p0[cur_row] += a2.x;
+                        if (VEC == 2) p1[cur_row] += a2.y;
+                        acc.zero();
+                        cur_row = (pk >> kColBits) & (kRW - 1);
+                    }
+                    acc.fma(cur.val(u), b[u]);
+                }
+                cur = nxt;
+            }
+        }
+        {
+            const float2 a2 = vec_to2<VEC>(acc);
+            p0[cur_row] += a2.x;
+            if (VEC == 2) p1[cur_row] += a2.y;
+        }
+        if (active) {
+            // static row numbers only: the accumulators stay in registers
+            auto emit = [&](uint32_t r, Vec<VEC> s) {
+                if (r >= task.n_rows) return;
+                const uint32_t dst = task_rows[(size_t)t * kRW + r];
+                if (dst & kSlotFlag) {
+                    s.store(partial + (size_t)(dst & ~kSlotFlag) * d + col);
+                    return;
+                }
+                float *cp = C + (size_t)dst * ldc + col;
+                // epilogue: alpha, beta (C is only read when beta != 0), optional leaky-ReLU
+                Vec<VEC> c0; c0.zero();
+                if (beta != 0.f) c0 = Vec<VEC>::load(cp);
+                s.map(reinterpret_cast<const float *>(&c0), [=](float x, float c) {
+                    float o = alpha * x;
+                    if (beta != 0.f) o = fmaf(beta, c, o);
+                    return (flags & MGGCN_SPMM_LEAKY_RELU) ? lrelu(o, slope) : o;
+                });
+                s.store(cp);
+            };
+            emit(0, vec_from2<VEC>(MGGCN_ROWS_GET(0)));   emit(1, vec_from2<VEC>(MGGCN_ROWS_GET(1)));
+            emit(2, vec_from2<VEC>(MGGCN_ROWS_GET(2)));   emit(3, vec_from2<VEC>(MGGCN_ROWS_GET(3)));
+            emit(4, vec_from2<VEC>(MGGCN_ROWS_GET(4)));   emit(5, vec_from2<VEC>(MGGCN_ROWS_GET(5)));
+            emit(6, vec_from2<VEC>(MGGCN_ROWS_GET(6)));   emit(7, vec_from2<VEC>(MGGCN_ROWS_GET(7)));
+            emit(8, vec_from2<VEC>(MGGCN_ROWS_GET(8)));   emit(9, vec_from2<VEC>(MGGCN_ROWS_GET(9)));
+            emit(10, vec_from2<VEC>(MGGCN_ROWS_GET(10))); emit(11, vec_from2<VEC>(MGGCN_ROWS_GET(11)));
+            emit(12, vec_from2<VEC>(MGGCN_ROWS_GET(12))); emit(13, vec_from2<VEC>(MGGCN_ROWS_GET(13)));
+            emit(14, vec_from2<VEC>(MGGCN_ROWS_GET(14))); emit(15, vec_from2<VEC>(MGGCN_ROWS_GET(15)));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sweep_combine_kernel(
+    const SweepSplitRow *__restrict__ rows, uint32_t n_split, const float *__restrict__ partial,
+    float *__restrict__ C, size_t ldc, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave =
+        __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wave >= n_split) return;
+    const SweepSplitRow sr = rows[wave];
+    for (uint32_t col = lane; col < d; col += 64) {
+        float acc = 0.f;
+        for (uint32_t s = 0; s < sr.n_slots; s++) acc += partial[(size_t)(sr.first_slot + s) * d + col];
+        float o = alpha * acc;
+        float *cp = C + (size_t)sr.row * ldc + col;
+        if (beta != 0.f) o = fmaf(beta, *cp, o);
+        if (flags & MGGCN_SPMM_LEAKY_RELU) o = lrelu(o, slope);
+        *cp = o;
+    }
+}
+
+uint32_t env_u32(const char *name, uint32_t dflt) {
+    const char *s = std::getenv(name);
+    if (!s || !*s) return dflt;
+    return (uint32_t)std::strtoul(s, nullptr, 10);
+}
+
+struct VRow {
+    uint32_t row, beg, end, dst;
+};
+
+}  // namespace
+
+struct SweepPlan {
+    uint32_t n_rows = 0, n_cols = 0, max_d = 0;
+    uint32_t n_tasks = 0, round_tasks = 0, n_split_rows = 0, n_slots = 0;
+    SweepTask *d_tasks = nullptr;
+    uint2 *d_entries = nullptr;
+    uint32_t *d_task_rows = nullptr;
+    SweepSplitRow *d_split = nullptr;
+    float *d_partial = nullptr;
+    size_t bytes = 0;
+};
+
+SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
+                            const uint32_t *indices, const float *values, uint32_t max_d) {
+    if (!n_rows || !indices || !values) return nullptr;
+    if (n_cols > kColMask) return nullptr;                          // column does not fit the packed entry
+    static_assert(kRW == 16, "4 row bits in the packed entry");
+    const uint64_t nnz = (uint64_t)indptr[n_rows] - indptr[0];
+    if (nnz < env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20)) return nullptr;   // small graphs: row-split is fine
+    const uint32_t panel_rows = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 4096u));
+
+    // resident waves per launch ("round").  Registers would admit 6 blocks of 4 waves per CU
+    // (56 VGPRs; ~106 SGPRs -> floor(800 / (ceil(sgpr/16)*16 + 16)) = 6, MI355X_MICROARCH.md
+    // residency rule), but FEWER waves keep the sweep tighter: the spread of the waves over the
+    // column space is what decides the L2 hit rate.  Measured on the Reddit shape, d = 128
+    // (profiles/experiments/sweep_vs_rowsplit.py): 2 blocks/CU 3.96 ms, 3 -> 3.34 ms, 4 -> 4.0,
+    // 5 -> 4.0, 6 -> 4.4 (row-split kernel: 5.96 ms).
+    const uint32_t blocks_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 3u), 8u));
+    const uint32_t round_tasks = kNumCU * blocks_per_cu * kWavesPerBlock;
+
+    // 1. virtual rows: slices of heavy rows get partial-sum slots
+    const uint32_t t_est = (n_rows + kRW - 1) / kRW;
+    const uint32_t target = (uint32_t)std::max<uint64_t>(1, nnz / t_est);
+    const uint32_t split = std::max<uint32_t>(256u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_SPLIT", target / 2), 1u << 20));
+    std::vector<VRow> vrows;
+    vrows.reserve((size_t)n_rows + 4096);
+    std::vector<SweepSplitRow> split_rows;
+    uint32_t n_slots = 0;
+    for (uint32_t r = 0; r < n_rows; r++) {
+        const uint32_t b = indptr[r], e = indptr[r + 1];
+        MGGCN_REQUIRE(e >= b, "indptr must be non-decreasing");
+        const uint32_t len = e - b;
+        if (len <= split + split / 2) {
+            vrows.push_back({r, b, e, r});
+        } else {
+            const uint32_t parts = (len + split - 1) / split;
+            split_rows.push_back({r, n_slots, parts, 0});
+            for (uint32_t k = 0; k < parts; k++) {
+                const uint32_t kb = b + (uint32_t)((uint64_t)len * k / parts);
+                const uint32_t ke = b + (uint32_t)((uint64_t)len * (k + 1) / parts);
+                vrows.push_back({r, kb, ke, kSlotFlag | n_slots++});
+            }
+        }
+    }
+    // 2. tasks: equal-work bins of <= RW virtual rows (longest first into the lightest bin)
+    uint32_t T = (uint32_t)((vrows.size() + kRW - 1) / kRW);
+    if (T > round_tasks) T = (T + round_tasks - 1) / round_tasks * round_tasks;
+    T = std::max<uint32_t>(T, 1u);
+    std::vector<uint32_t> order(vrows.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return (vrows[a].end - vrows[a].beg) > (vrows[b].end - vrows[b].beg);
+    });
+    std::vector<std::vector<uint32_t>> bins(T);
+    std::vector<uint64_t> load(T, 0);
+    using HeapItem = std::pair<uint64_t, uint32_t>;        // (load, task): smallest load first, then lowest id
+    std::priority_queue<HeapItem, std::vector<HeapItem>, std::greater<HeapItem>> heap;
+    for (uint32_t t = 0; t < T; t++) heap.push({0, t});
+    for (uint32_t vi : order) {
+        MGGCN_REQUIRE(!heap.empty(), "sweep plan: task capacity exhausted");
+        const HeapItem top = heap.top();
+        heap.pop();
+        const uint32_t t = top.second;
+        bins[t].push_back(vi);
+        load[t] += vrows[vi].end - vrows[vi].beg;
+        if (bins[t].size() < (size_t)kRW) heap.push({load[t], t});
+    }
+    // 3. entry stream per task, sorted by (column panel, local row), original order inside a run
+    std::vector<SweepTask> tasks(T);
+    std::vector<uint32_t> task_rows((size_t)T * kRW, 0u);
+    uint64_t off = 0;
+    for (uint32_t t = 0; t < T; t++) {
+        tasks[t].beg = (uint32_t)off;
+        off += (load[t] + 7) / 8 * 8;                 // whole 8-entry (64-byte) batches
+        tasks[t].end = (uint32_t)off;
+        tasks[t].n_rows = (uint32_t)bins[t].size();
+        tasks[t].pad = 0;
+        for (size_t r = 0; r < bins[t].size(); r++) task_rows[(size_t)t * kRW + r] = vrows[bins[t][r]].dst;
+    }
+    MGGCN_REQUIRE(off < (1ull << 32), "sweep plan: entry stream exceeds 32-bit offsets");
+    const uint64_t n_entries = off;
+    std::vector<uint2> entries(n_entries);
+    const uint32_t n_panels = (n_cols + panel_rows - 1) / panel_rows;
+    unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (const char *s = std::getenv("MGGCN_HOST_THREADS")) hw = std::max(1u, (unsigned)std::strtoul(s, nullptr, 10));
+    const unsigned NT = nnz > (1u << 22) ? hw : 1u;
+    auto worker = [&](unsigned tid) {
+        std::vector<uint32_t> cnt((size_t)n_panels * kRW + 1), cnt_start;
+        for (uint32_t t = tid; t < T; t += NT) {
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            const auto &bin = bins[t];
+            for (size_t r = 0; r < bin.size(); r++) {
+                const VRow &v = vrows[bin[r]];
+                for (uint32_t e = v.beg; e < v.end; e++) cnt[(size_t)(indices[e] / panel_rows) * kRW + r + 1]++;
+            }
+            for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+            uint2 *out = entries.data() + tasks[t].beg;
+            std::vector<uint32_t> &run_start = cnt_start;
+            run_start.assign(cnt.begin(), cnt.end());            // bucket start offsets (before filling)
+            for (size_t r = 0; r < bin.size(); r++) {
+                const VRow &v = vrows[bin[r]];
+                for (uint32_t e = v.beg; e < v.end; e++) {
+                    const uint32_t c = indices[e];
+                    MGGCN_REQUIRE(c < n_cols, "column index out of range");
+                    const uint32_t at = cnt[(size_t)(c / panel_rows) * kRW + r]++;
+                    uint32_t vb;
+                    std::memcpy(&vb, &values[e], 4);
+                    out[at] = make_uint2((((uint32_t)r & (kRW - 1)) << kColBits) | c, vb);
+                }
+            }
+            // mark the first entry of every non-empty (panel,row) bucket
+            const uint32_t real = (uint32_t)load[t], padded = tasks[t].end - tasks[t].beg;
+            for (size_t k = 0; k + 1 < run_start.size(); k++)
+                if (run_start[k + 1] > run_start[k]) out[run_start[k]].x |= kRunFlag;
+            // padding: zero-valued copies of the last entry without the run flag (no extra fold,
+            // same column -> an L2 hit); an empty task has no batches at all
+            for (uint32_t k = real; k < padded; k++) out[k] = make_uint2(out[real - 1].x & ~kRunFlag, 0u);
+        }
+    };
+    if (NT <= 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < NT; i++) th.emplace_back(worker, i);
+        for (auto &x : th) x.join();
+    }
+
+    auto *p = new SweepPlan;
+    p->n_rows = n_rows; p->n_cols = n_cols; p->max_d = max_d;
+    p->n_tasks = T; p->round_tasks = round_tasks;
+    p->n_split_rows = (uint32_t)split_rows.size(); p->n_slots = n_slots;
+    const size_t tb = tasks.size() * sizeof(SweepTask), eb = entries.size() * sizeof(uint2);
+    const size_t rb = task_rows.size() * sizeof(uint32_t), sb = split_rows.size() * sizeof(SweepSplitRow);
+    const size_t pb = (size_t)n_slots * max_d * sizeof(float);
+    MGGCN_CHECK_HIP(hipMalloc(&p->d_tasks, tb));
+    MGGCN_CHECK_HIP(hipMemcpy(p->d_tasks, tasks.data(), tb, hipMemcpyHostToDevice));
+    MGGCN_CHECK_HIP(hipMalloc(&p->d_entries, std::max<size_t>(eb, 8)));
+    if (eb) MGGCN_CHECK_HIP(hipMemcpy(p->d_entries, entries.data(), eb, hipMemcpyHostToDevice));
+    MGGCN_CHECK_HIP(hipMalloc(&p->d_task_rows, rb));
+    MGGCN_CHECK_HIP(hipMemcpy(p->d_task_rows, task_rows.data(), rb, hipMemcpyHostToDevice));
+    if (sb) {
+        MGGCN_CHECK_HIP(hipMalloc(&p->d_split, sb));
+        MGGCN_CHECK_HIP(hipMemcpy(p->d_split, split_rows.data(), sb, hipMemcpyHostToDevice));
+    }
+    if (pb) MGGCN_CHECK_HIP(hipMalloc(&p->d_partial, pb));
+    p->bytes = tb + eb + rb + sb + pb;
+    return p;
+}
+
+void sweep_plan_destroy(SweepPlan *p) {
+    if (!p) return;
+    if (p->d_tasks) MGGCN_CHECK_HIP(hipFree(p->d_tasks));
+    if (p->d_entries) MGGCN_CHECK_HIP(hipFree(p->d_entries));
+    if (p->d_task_rows) MGGCN_CHECK_HIP(hipFree(p->d_task_rows));
+    if (p->d_split) MGGCN_CHECK_HIP(hipFree(p->d_split));
+    if (p->d_partial) MGGCN_CHECK_HIP(hipFree(p->d_partial));
+    delete p;
+}
+
+size_t sweep_plan_bytes(const SweepPlan *p) { return p ? p->bytes : 0; }
+uint32_t sweep_plan_tasks(const SweepPlan *p) { return p ? p->n_tasks : 0; }
+uint32_t sweep_plan_split_rows(const SweepPlan *p) { return p ? p->n_split_rows : 0; }
+
+bool sweep_supports(const SweepPlan *p, uint32_t d, size_t ldb, size_t ldc, const void *B, const void *C) {
+    if (!p) return false;
+    if (p->n_slots && d > p->max_d) return false;
+    // the row gathers address B through a 32-bit buffer descriptor
+    if ((uint64_t)p->n_cols * ldb * sizeof(float) > 0xFFFFFFFFull) return false;
+    (void)ldc; (void)B; (void)C;
+    return true;
+}
+
+void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb, float *C, size_t ldc,
+                  uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    // float2 lanes need 8-byte aligned rows; otherwise one column per lane
+    const bool vec2 = d > 64 && d % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 &&
+                      (reinterpret_cast<uintptr_t>(B) & 7u) == 0 && (reinterpret_cast<uintptr_t>(C) & 7u) == 0;
+    const uint32_t b_bytes = (uint32_t)((uint64_t)p->n_cols * ldb * sizeof(float));
+    const uint32_t row_bytes = (uint32_t)(ldb * sizeof(float));
+    for (uint32_t t0 = 0; t0 < p->n_tasks; t0 += p->round_tasks) {
+        const uint32_t n_launch = std::min(p->round_tasks, p->n_tasks - t0);
+        const dim3 grid((n_launch + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+        if (vec2)
+            hipLaunchKernelGGL((spmm_sweep_kernel<2>), grid, block, 0, st, p->d_tasks, t0, n_launch,
+                               p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
+                               alpha, beta, flags, slope);
+        else
+            hipLaunchKernelGGL((spmm_sweep_kernel<1>), grid, block, 0, st, p->d_tasks, t0, n_launch,
+                               p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
+                               alpha, beta, flags, slope);
+        MGGCN_CHECK_LAUNCH();
+    }
+    if (p->n_split_rows) {
+        hipLaunchKernelGGL(sweep_combine_kernel, dim3((p->n_split_rows + 3) / 4), dim3(256), 0, st, p->d_split,
+                           p->n_split_rows, p->d_partial, C, ldc, d, alpha, beta, flags, slope);
+        MGGCN_CHECK_LAUNCH();
+    }
+}

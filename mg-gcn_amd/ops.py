@@ -26,6 +26,7 @@ class spmm_buffer:
 
     def num_items(self) -> int: return self.lib.mggcn_spmm_plan_num_items(self.handle)
     def num_split_rows(self) -> int: return self.lib.mggcn_spmm_plan_num_split_rows(self.handle)
+    def num_sweep_tasks(self) -> int: return self.lib.mggcn_spmm_plan_num_sweep_tasks(self.handle)
     def nbytes(self) -> int: return self.lib.mggcn_spmm_plan_bytes(self.handle)
 
     def __del__(self):
@@ -43,7 +44,8 @@ def get_matmul_buffer(ctx: context, A: csr_matrix, B: dn_matrix, C: dn_matrix, a
     _req(A.m() == B.n(), "A.m() != B.n()")
     _req(A.n() == C.n() and B.m() == C.m(), "C shape mismatch")
     ctx.set()
-    h = ctx.lib.mggcn_spmm_plan_create(A.n(), A.m(), A.indptr.ctypes.data, max(int(max_d or 0), B.m()))
+    h = ctx.lib.mggcn_spmm_plan_create(A.n(), A.m(), A.indptr.ctypes.data, A.indices.ctypes.data,
+                                       A.data.ctypes.data, max(int(max_d or 0), B.m()))
     return spmm_buffer(ctx.lib, h)
 
 

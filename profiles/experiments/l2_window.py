@@ -17,7 +17,9 @@ d = 128
 B = pkg.dn_matrix.from_numpy(np.random.default_rng(0).standard_normal((n, d), dtype=np.float32))
 C = pkg.dn_matrix(n, d)
 rng = np.random.default_rng(1)
-for W in [2048, 4096, 8192, 16384, 32768, 65536, n]:
+ALGO = os.environ.get("EXP_ALGO", "rowsplit")
+os.environ["MGGCN_SPMM_ALGO"] = ALGO
+for W in [int(x) for x in os.environ.get("EXP_WINDOWS", "2048,4096,8192,16384,32768,65536,%d" % n).split(",")]:
     cols = rng.integers(0, W, size=ix.shape[0], dtype=np.uint32)
     A = pkg.csr_matrix(ip, cols, dv, n)
     buf = pkg.get_matmul_buffer(ctx, A, B, C)
@@ -31,5 +33,5 @@ for W in [2048, 4096, 8192, 16384, 32768, 65536, n]:
     ctx.sync()
     ctx.register_timer("t", "a", "b")
     ms = ctx.measure("t") / 5
-    print(f"window {W:7d} rows = {W*512/2**20:7.2f} MiB : {ms:7.3f} ms/SpMM, gather {ix.shape[0]*512/ms/1e9:8.1f} GB/s", flush=True)
+    print(f"{ALGO} window {W:7d} rows = {W*512/2**20:7.2f} MiB : {ms:7.3f} ms/SpMM, gather {ix.shape[0]*512/ms/1e9:8.1f} TB/s", flush=True)
     del A, buf

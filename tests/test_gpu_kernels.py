@@ -18,9 +18,12 @@ def relerr(got, want):
 
 
 def rowwise_relerr(got, want):
+    """max over rows of (row's max abs error) / (row's max abs value), the row scale floored at
+    1 % of the global scale so that a row that cancels to ~0 (d = 1!) is judged against the
+    magnitude of the numbers that were actually summed"""
     want = np.asarray(want, dtype=np.float64)
     got = np.asarray(got, dtype=np.float64)
-    den = np.abs(want).max(axis=1) + 1e-30
+    den = np.maximum(np.abs(want).max(axis=1), 1e-2 * np.abs(want).max()) + 1e-30
     return float((np.abs(got - want).max(axis=1) / den).max())
 
 
@@ -254,3 +257,69 @@ def test_adam_fused_equals_chain_equals_oracle(pkg, oracle, ctx):
             ol.adam_update(1e-2, 0.9, 0.999, 5e-4, 1e-8)
             assert relerr(lin.W.numpy(), ol.W) <= 1e-5
             assert relerr(lin.b.numpy(), ol.b) <= 1e-5
+
+
+# ---- column-panel sweep form of the SpMM (spmm_sweep.hip) ---------------------------------
+@pytest.fixture
+def force_sweep(monkeypatch):
+    """Small test matrices would fall back to the row-split kernels: force the sweep form
+    and a tiny panel so that the (panel, row) ordering of the entry streams is exercised."""
+    monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_NNZ", "1")
+    monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS", "64")
+    monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
+
+
+@pytest.mark.parametrize("d", [1, 8, 41, 48, 64, 66, 128, 130, 256, 608])
+def test_sweep_spmm_widths(pkg, oracle, ctx, force_sweep, d):
+    n = 1500
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 60_000, 4000, seed=100 + d)
+    dv = np.random.default_rng(d).random(dv.shape[0], dtype=np.float32)
+    A, Ao = _csr(pkg, oracle, ip, ix, dv, n)
+    rng = np.random.default_rng(d + 1)
+    B = rng.standard_normal((n, d), dtype=np.float32)
+    C0 = rng.standard_normal((n, d), dtype=np.float32)
+    for alpha, beta, flags in [(1.0, 0.0, 0), (0.5, 2.0, 0), (1.0, 1.0, 1), (1.0, 0.0, 1)]:
+        got, buf = _run_spmm(pkg, ctx, A, B, C0, alpha, beta, flags=flags)
+        assert buf.num_sweep_tasks() > 0
+        want = oracle.spmm(Ao, B, C0.copy(), alpha, beta, f64acc=True)
+        if flags:
+            want = oracle.leaky_relu_forward(want)
+        assert rowwise_relerr(got, want) <= TOL, (d, alpha, beta, flags)
+
+
+def test_sweep_spmm_edge_cases_and_reproducibility(pkg, oracle, ctx, force_sweep):
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 7, 8, 9, 0, 128, 129, 700, 2, 0, 0, 5000, 3]     # empty rows, batch boundaries, a split row
+    ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    m = 300
+    ix = rng.integers(0, m, size=int(ip[-1]), dtype=np.uint32)
+    dv = rng.standard_normal(int(ip[-1])).astype(np.float32)
+    A, Ao = _csr(pkg, oracle, ip, ix, dv, m)
+    for d in (128, 41):
+        B = rng.standard_normal((m, d)).astype(np.float32)
+        C0 = np.full((len(lens), d), np.nan, dtype=np.float32)
+        got, buf = _run_spmm(pkg, ctx, A, B, C0, 1.0, 0.0)
+        assert buf.num_sweep_tasks() > 0
+        want = oracle.spmm(Ao, B, f64acc=True)
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+        assert (got[[0, 5, 10, 11]] == 0).all()
+        again, _ = _run_spmm(pkg, ctx, A, B, C0, 1.0, 0.0)
+        np.testing.assert_array_equal(got, again)                  # fixed fold order -> bitwise equal
+
+
+def test_sweep_equals_rowsplit_on_a_big_graph(pkg, ctx, monkeypatch):
+    """> 2^20 non-zeros: the sweep form is picked by default; compare with the row-split form."""
+    n, d = 40_000, 128
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 3_000_000, 9000, seed=4)
+    A = pkg.csr_matrix(ip, ix, dv, n)
+    A.normalize(True)
+    B = np.random.default_rng(3).standard_normal((n, d), dtype=np.float32)
+    z = np.zeros((n, d), np.float32)
+    monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
+    s, bs = _run_spmm(pkg, ctx, A, B, z, 1.0, 0.0)
+    assert bs.num_sweep_tasks() > 0
+    monkeypatch.setenv("MGGCN_SPMM_ALGO", "rowsplit")
+    r, br = _run_spmm(pkg, ctx, A, B, z, 1.0, 0.0)
+    assert br.num_sweep_tasks() == 0
+    assert rowwise_relerr(s, r) <= 2e-5
