@@ -104,6 +104,33 @@ def split_local_remote(A: csr_matrix, row_begin: int, row_end: int) -> Tuple[csr
 
 
 # --------------------------------------------------------------------------------------
+# host-staged collectives (gloo): CPU rehearsal of the exchange step and the fallback when
+# several ranks share one GPU.  Pure torch.distributed on CPU tensors -- no GPU needed.
+# --------------------------------------------------------------------------------------
+def gloo_all_gather_rows(host_shard, P: int, group=None):
+    """[rows x d] per rank -> [P*rows x d] on every rank, rank order (== ncclAllGather /
+    the P broadcasts of reference src/dist_matrix.hpp:458-467)."""
+    torch, dist = _torch(), _dist()
+    parts = [torch.empty_like(host_shard) for _ in range(P)]
+    dist.all_gather(parts, host_shard.contiguous(), group=group)
+    return torch.cat(parts, dim=0)
+
+
+def gloo_broadcast_rows(host_shard, shape, dtype, root: int, rank: int, group=None):
+    """one round of the reference's schedule: shard `root` to everybody"""
+    torch, dist = _torch(), _dist()
+    buf = host_shard.contiguous() if rank == root else torch.empty(tuple(shape), dtype=dtype)
+    src = dist.get_global_rank(group, root) if group is not None else root
+    dist.broadcast(buf, src=src, group=group)
+    return buf
+
+
+def gloo_all_reduce_sum(host_flat, group=None):
+    _dist().all_reduce(host_flat, group=group)
+    return host_flat
+
+
+# --------------------------------------------------------------------------------------
 class dist_context:
     """reference src/dist_matrix.hpp:12-90, one rank's view.  ``overlap`` selects the
     comm stream exactly like bcast_stream_id() (:20-22); ``-S`` on the CLI clears it."""
@@ -144,12 +171,10 @@ class dist_context:
             with torch.cuda.stream(self.ctx.cuda_streams[stream_id]):
                 work = dist.all_gather_into_tensor(out, shard, group=self.group, async_op=True)
             return _Pending(self, work, None, None)
-        # gloo (CPU rehearsal / several ranks sharing one GPU): stage through the host
+        # gloo (several ranks sharing one GPU): stage through the host
+        self.ctx.cuda_streams[0].synchronize()
         self.ctx.cuda_streams[stream_id].synchronize()
-        host = shard.detach().cpu().contiguous()
-        parts = [torch.empty_like(host) for _ in range(self.P)]
-        dist.all_gather(parts, host, group=self.group)
-        return _Pending(self, None, torch.cat(parts, dim=0), out)
+        return _Pending(self, None, gloo_all_gather_rows(shard.detach().cpu(), self.P, self.group), out)
 
     def broadcast_rows(self, shard, out, root: int, stream_id: int):
         torch, dist = _torch(), _dist()
@@ -160,10 +185,10 @@ class dist_context:
                     out.copy_(shard)
                 work = dist.broadcast(out, src=src, group=self.group, async_op=True)
             return _Pending(self, work, None, None)
+        self.ctx.cuda_streams[0].synchronize()
         self.ctx.cuda_streams[stream_id].synchronize()
-        host = shard.detach().cpu().contiguous() if self.rank == root else torch.empty(
-            tuple(out.shape), dtype=out.dtype)
-        dist.broadcast(host, src=src, group=self.group)
+        host = gloo_broadcast_rows(shard.detach().cpu() if self.rank == root else None, out.shape,
+                                   out.dtype, root, self.rank, self.group)
         return _Pending(self, None, host, out)
 
     def all_reduce_sum(self, tensors: Sequence, stream_id: int = 0) -> None:
@@ -177,9 +202,7 @@ class dist_context:
                 dist.all_reduce(flat, group=self.group)
             else:
                 st.synchronize()
-                host = flat.cpu()
-                dist.all_reduce(host, group=self.group)
-                flat.copy_(host)
+                flat.copy_(gloo_all_reduce_sum(flat.cpu(), self.group))
             off = 0
             for t in tensors:
                 t.copy_(flat[off:off + t.numel()].view_as(t))

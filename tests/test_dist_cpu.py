@@ -1,0 +1,122 @@
+"""World-size-2 (and 4) `gloo` rehearsal of the 1D-row-partition path on CPU: the host-side
+partitioning (block split, diagonal/remote split) and the exchange step (all-gather, the
+reference's broadcast rounds, gradient all-reduce) run for real through torch.distributed;
+the arithmetic between them is the oracle's SpMM (the HIP kernels need a GPU -- their
+multi-rank test is tests/test_dist_gpu.py).  Checked against the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _graph(n, seed):
+    import scipy.sparse as sp
+    M = sp.random(n, n, density=0.08, format="csr", dtype=np.float32, random_state=seed)
+    M = sp.csr_matrix(M + sp.eye(n, dtype=np.float32, format="csr"))
+    M.data = (M.data + 0.25).astype(np.float32)
+    return M.indptr.astype(np.uint32), M.indices.astype(np.uint32), M.data
+
+
+def _worker(rank, P, port, n, d, out_q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import __graft_entry__ as ge
+    import oracle as orc
+    pkg = ge.load_package()
+    D = pkg.dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=P)
+    try:
+        ip, ix, dv = _graph(n, 3)
+        A = pkg.csr_matrix(ip, ix, dv, n)
+        A.normalize(True)
+        p = D.partition_bounds(n, P)
+        blocks = D.split_row_block(A, p[rank], p[rank + 1], p)
+        diag, remote = D.split_local_remote(A, p[rank], p[rank + 1])
+        rng = np.random.default_rng(11)
+        B = rng.standard_normal((n, d)).astype(np.float32)       # same on every rank
+        mine = torch.from_numpy(B[p[rank]:p[rank + 1]].copy())
+        as_o = lambda m: orc.Csr(m.indptr, m.indices, m.data, m.m())
+
+        # all-gather schedule: local block first, then the merged remote blocks (beta = 1)
+        gathered = D.gloo_all_gather_rows(mine, P).numpy()
+        np.testing.assert_array_equal(gathered, B)
+        C = orc.spmm(as_o(diag), mine.numpy())
+        orc.spmm(as_o(remote), gathered, C, 1.0, 1.0)
+
+        # the reference's rounds: broadcast shard i, multiply block (rank, i), accumulate in order
+        R = np.empty_like(C)
+        for i in range(P):
+            shard = D.gloo_broadcast_rows(mine if rank == i else None, (p[i + 1] - p[i], d), torch.float32, i, rank)
+            orc.spmm(as_o(blocks[i]), shard.numpy(), R, 1.0, 0.0 if i == 0 else 1.0)
+
+        # weight-gradient all-reduce: G_W = X^T G summed over ranks == full product
+        G = rng.standard_normal((n, 5)).astype(np.float32)
+        gw = torch.from_numpy(orc.gemm(B[p[rank]:p[rank + 1]], G[p[rank]:p[rank + 1]], A_T=True))
+        gw = D.gloo_all_reduce_sum(gw.reshape(-1)).reshape(d, 5).numpy()
+        out_q.put((rank, C, R, gw))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_partition_and_exchange_match_single_process(oracle, pkg, P):
+    n, d = 64, 16
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, P, port, n, d, q)) for r in range(P)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=120) for _ in range(P)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    res.sort(key=lambda t: t[0])
+
+    ip, ix, dv = _graph(n, 3)
+    A = oracle.Csr(ip, ix, dv, n)
+    oracle.normalize(A, True)
+    B = np.random.default_rng(11).standard_normal((n, d)).astype(np.float32)
+    full = oracle.spmm(A, B, f64acc=True)
+    p = [i * n // P for i in range(P + 1)]
+    blocks = oracle.block_split(A, p, p)
+    rounds = oracle.dist_spmm(blocks, [B[p[j]:p[j + 1]] for j in range(P)])
+    G = np.random.default_rng(11)
+    G.standard_normal((n, d))
+    Gm = G.standard_normal((n, 5)).astype(np.float32)
+    gw_full = oracle.gemm(B, Gm, A_T=True, f64acc=True)
+    for rank, C, R, gw in res:
+        np.testing.assert_allclose(C, full[p[rank]:p[rank + 1]], rtol=1e-5, atol=1e-6)     # regrouped sum
+        np.testing.assert_array_equal(R, rounds[rank])                                      # same order: bit-exact
+        np.testing.assert_allclose(gw, gw_full, rtol=1e-5, atol=1e-5)
+
+
+def test_local_remote_split_reassembles(pkg, oracle):
+    D = pkg.dist
+    n = 48
+    ip, ix, dv = _graph(n, 7)
+    A = pkg.csr_matrix(ip, ix, dv, n)
+    dense = A.as_dn()
+    for P in (2, 3, 4):
+        p = D.partition_bounds(n, P)
+        for r in range(P):
+            diag, remote = D.split_local_remote(A, p[r], p[r + 1])
+            assert (diag.n(), diag.m()) == (n // P, n // P) and (remote.n(), remote.m()) == (n // P, n)
+            want = dense[p[r]:p[r + 1]].copy()
+            np.testing.assert_array_equal(diag.as_dn(), want[:, p[r]:p[r + 1]])
+            want[:, p[r]:p[r + 1]] = 0
+            np.testing.assert_array_equal(remote.as_dn(), want)
+            assert diag.nnz() + remote.nnz() == int(A.indptr[p[r + 1]] - A.indptr[p[r]])
+    with pytest.raises(ValueError):
+        D.partition_bounds(10, 4)            # n % P != 0 (reference asserts, dist_matrix.hpp:428)
