@@ -1,0 +1,53 @@
+/*
+ * mggcn_comm.h -- C ABI of libmggcn_comm.so: the collectives of the single-process,
+ * P-GPU form of the 1D row partition, over RCCL (xGMI).
+ *
+ * Replaces the reference's NCCL call sites (citations relative to the reference tree):
+ *   ncclCommInitAll                      src/dist_matrix.hpp:26-31
+ *   dist_row_dn_matrix::bcast            src/dist_matrix.hpp:458-467  (group of P ncclBroadcast)
+ *   repl_dn_matrix::allreduce            src/dist_matrix.hpp:587-592  (group of P ncclAllReduce)
+ *   repl_dn_matrix ctor / init broadcast src/dist_matrix.hpp:573-580, :601-609
+ * plus the exchange the MI355X build prefers: ONE all-gather of the row shards instead of P
+ * broadcasts (every GPU pushes to its 7 xGMI peers at once).
+ *
+ * Like the reference this is the one-host-thread model: every function takes one buffer and
+ * one stream PER GPU (arrays of length P, index = device ordinal in the communicator) and
+ * issues the P per-communicator calls inside one ncclGroupStart/End.  Enqueue-only; fail-fast
+ * (message + exit) like CHECK_NCCL (src/mg_gcn.hpp:60-68).  fp32 payloads only.
+ *
+ * Kept in its own library so that a process that already hosts an RCCL (e.g. PyTorch's
+ * bundled one) never loads a second copy: the one-process-per-GPU host layer uses
+ * torch.distributed instead and does not link this file.
+ */
+#ifndef MGGCN_COMM_H_
+#define MGGCN_COMM_H_
+
+#include <stddef.h>
+
+#include "mggcn.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mggcn_comm mggcn_comm;
+
+/* ncclCommInitAll over devices 0..P-1 (devices == NULL) or the given ordinals. */
+mggcn_comm *mggcn_comm_init_all(int P, const int *devices);
+void mggcn_comm_destroy(mggcn_comm *comm);
+int mggcn_comm_size(const mggcn_comm *comm);
+
+/* recv[j] <- send_root (count floats) on every GPU j; send_root lives on GPU `root`. */
+void mggcn_comm_broadcast_f32(mggcn_comm *comm, const float *send_root, float *const *recv, size_t count,
+                              int root, const mggcn_stream_t *streams);
+/* recv[j][i*count .. (i+1)*count) <- send[i] for all i, on every GPU j. */
+void mggcn_comm_allgather_f32(mggcn_comm *comm, const float *const *send, float *const *recv, size_t count,
+                              const mggcn_stream_t *streams);
+/* bufs[j] <- sum_i bufs[i], in place, on every GPU j. */
+void mggcn_comm_allreduce_sum_f32(mggcn_comm *comm, float *const *bufs, size_t count,
+                                  const mggcn_stream_t *streams);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGGCN_COMM_H_ */

@@ -1,0 +1,602 @@
+// gcn.hpp -- the layer API of the reference (src/gcn.hpp) over the HIP engine.
+//
+// sparse_linear (:13-48), dist_sparse_linear (:50-86), linear (:88-189), dist_row_linear
+// (:191-296), gcn_layer (:411-518), dist_gcn_layer (:520-637), softmax (:639-676),
+// softmax_cross_entropy_loss (:769-823), dist_row_softmax_cross_entropy_loss (:872-935),
+// gcn (:937-995), dist_gcn (:997-1056): same names, constructor arguments, members, buffer
+// aliasing (model-wide HW_buffer; per-layer AHW_buffer holding AHW forward / G_out backward),
+// layer-order rule (out <= in: GEMM first), skipped first-layer backward SpMM, timer names.
+// `fused` (default on in gcn / dist_gcn) folds leaky-ReLU into the SpMM epilogue and uses the
+// one-pass loss and one-launch Adam kernels; fused = false replays the reference's launches.
+#pragma once
+
+#include <cmath>
+#include <numeric>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "dist_matrix.hpp"
+#include "matrix.hpp"
+#include "ops.hpp"
+
+template <typename x_t, typename v_t, typename r_t>
+class sparse_linear {
+    using csr_t = csr_matrix<x_t, v_t, r_t>;
+    using dn_t = dn_matrix<r_t>;
+    std::string name;
+    csr_t A, A_T;
+    spmm_buffer ext_buffer, ext_buffer2;
+
+public:
+    sparse_linear(std::string name, csr_t A, csr_t A_T) : name(name), A(A), A_T(A_T) {}
+
+    void operator()(context ctx, dn_t B, dn_t C, bool discard = true, uint32_t flags = 0) {
+        if (!ext_buffer) ext_buffer = get_matmul_buffer(ctx, A, B, C);      // plan is width-independent up to 128+
+        ctx.record(name + "0_0_matmul-spmm", 0);
+        matmul(ctx, A, B, C, ext_buffer, (r_t)1, discard ? (r_t)0 : (r_t)1, flags);
+        ctx.record(name + "0_1_matmul-spmm", 0);
+        ctx.register_timer(name + "0_matmul-spmm", name + "0_0_matmul-spmm", name + "0_1_matmul-spmm");
+    }
+
+    void backward(context ctx, dn_t G, dn_t G_out, bool discard = true) {
+        if (!ext_buffer2) ext_buffer2 = get_matmul_buffer(ctx, A_T, G, G_out);
+        ctx.record(name + "1_0_matmul-spmm", 0);
+        matmul(ctx, A_T, G, G_out, ext_buffer2, (r_t)1, discard ? (r_t)0 : (r_t)1);
+        ctx.record(name + "1_1_matmul-spmm", 0);
+        ctx.register_timer(name + "1_matmul-spmm", name + "1_0_matmul-spmm", name + "1_1_matmul-spmm");
+    }
+};
+
+template <bool row_partition, typename x_t, typename v_t, typename r_t>
+class dist_sparse_linear {
+    static_assert(row_partition, "only the row partition is live in the reference CLI");
+    using csr_t = dist_row_csr_matrix<x_t, v_t, r_t>;
+    using dn_t = dist_row_dn_matrix<r_t>;
+    std::string name;
+    csr_t A, A_T;
+    std::vector<mggcn::device_ptr<r_t>> bcast_buffer, bcast_buffer2;
+    bool rounds;
+    std::size_t M = 0, M2 = 0;
+    dist_spmm_buffers ext, ext2;
+    bool have_ext = false, have_ext2 = false;
+
+    // receive buffers as matrices of the current width
+    std::vector<dn_t> round_views(const dist_context &ctx, const dn_t &B) const {
+        return {dn_t(ctx, B.n(), B.m(), bcast_buffer), dn_t(ctx, B.n(), B.m(), bcast_buffer2)};
+    }
+    std::vector<dn_matrix<r_t>> gather_views(const dist_context &ctx, const dn_t &B) const {
+        std::vector<dn_matrix<r_t>> g;
+        for (std::size_t j = 0; j < ctx.size(); j++) g.emplace_back(B.n(), B.m(), bcast_buffer[j]);
+        return g;
+    }
+
+public:
+    dist_sparse_linear(std::string name, csr_t A, csr_t A_T, std::vector<mggcn::device_ptr<r_t>> bcast_buffer,
+                       std::vector<mggcn::device_ptr<r_t>> bcast_buffer2, bool rounds = false)
+        : name(name), A(A), A_T(A_T), bcast_buffer(bcast_buffer), bcast_buffer2(bcast_buffer2), rounds(rounds) {}
+
+    void operator()(const dist_context ctx, dn_t B, dn_t C, bool discard = true, uint32_t flags = 0) {
+        if (!have_ext) { ext = get_matmul_buffer(ctx, A, B, C, rounds); have_ext = true; }
+        if (rounds) matmul(ctx, A, B, C, ext, round_views(ctx, B), (r_t)1, discard ? (r_t)0 : (r_t)1, name + "0_", flags);
+        else matmul_allgather(ctx, A, B, C, ext, gather_views(ctx, B), (r_t)1, discard ? (r_t)0 : (r_t)1, name + "0_", flags);
+    }
+
+    void backward(const dist_context ctx, dn_t G, dn_t G_out, bool discard = true) {
+        if (!have_ext2) { ext2 = get_matmul_buffer(ctx, A_T, G, G_out, rounds); have_ext2 = true; }
+        if (rounds) matmul(ctx, A_T, G, G_out, ext2, round_views(ctx, G), (r_t)1, discard ? (r_t)0 : (r_t)1, name + "1_");
+        else matmul_allgather(ctx, A_T, G, G_out, ext2, gather_views(ctx, G), (r_t)1, discard ? (r_t)0 : (r_t)1, name + "1_");
+    }
+};
+
+// shared Adam step of linear / dist_row_linear (reference src/gcn.hpp:146-172)
+template <typename r_t>
+void adam_step(context ctx, bool fused, dn_matrix<r_t> W, dn_matrix<r_t> G_W, dn_matrix<r_t> mW, dn_matrix<r_t> vW, dn_matrix<r_t> b,
+               dn_matrix<r_t> G_b, dn_matrix<r_t> mb, dn_matrix<r_t> vb, r_t lr, r_t beta1, r_t beta2, r_t wd, r_t eps, std::size_t step) {
+    const r_t bc1 = 1 - std::pow(beta1, step);
+    const r_t bc2 = 1 - std::pow(beta2, step);
+    if (fused) {
+        adam_fused(ctx, W, G_W, mW, vW, lr, beta1, beta2, wd, bc1, bc2, eps);
+        adam_fused(ctx, b, G_b, mb, vb, lr, beta1, beta2, (r_t)0, bc1, bc2, eps);
+        return;
+    }
+    axpy(ctx, W, G_W, wd);
+    axpby(ctx, G_W, mW, 1 - beta1, beta1);
+    axpby(ctx, G_b, mb, 1 - beta1, beta1);
+    aaxpby(ctx, G_W, vW, 1 - beta2, beta2);
+    aaxpby(ctx, G_b, vb, 1 - beta2, beta2);
+    adam_final(ctx, W, mW, vW, lr, bc1, bc2, eps);
+    adam_final(ctx, b, mb, vb, lr, bc1, bc2, eps);
+}
+
+template <typename r_t>
+class linear {
+    using dn_t = dn_matrix<r_t>;
+    std::string name;
+    dn_t W, G_W, mW, vW, b, G_b, mb, vb, X, ones;
+    bool backward_out, fused;
+    std::size_t step = 0;
+
+public:
+    linear(std::string name, std::size_t in, std::size_t out, bool backward_out = true, bool fused = false)
+        : name(name), W(in, out), G_W(in, out), b(1, out), G_b(1, out), backward_out(backward_out), fused(fused) {
+        W.init();
+        b.init(std::sqrt((r_t)1.0 / 3));
+    }
+
+    void setX(dn_t new_X) { X = new_X; }
+
+    void operator()(context ctx, dn_t X, dn_t XW, bool discard = true) {
+        broadcast_rows(ctx, b, XW, discard);
+        ctx.record(name + "0_0_matmul-gemm", 0);
+        matmul(ctx, X, W, XW, (r_t)1, (r_t)1);
+        ctx.record(name + "0_1_matmul-gemm", 0);
+        ctx.register_timer(name + "0_matmul-gemm", name + "0_0_matmul-gemm", name + "0_1_matmul-gemm");
+        this->X = X;
+    }
+
+    void backward(context ctx, dn_t G, dn_t G_out, bool discard = true) {
+        if (ones.n() != 1 || ones.m() != G.n()) { ones = dn_t(1, G.n()); ones.fill(1); }
+        ctx.record(name + "1_0_matmul-gemm", 0);
+        matmul(ctx, ones, G, G_b, (r_t)1, (r_t)0);
+        ctx.record(name + "1_1_matmul-gemm", 0);
+        matmul(ctx, X, G, G_W, (r_t)1, (r_t)0, true);
+        ctx.record(name + "1_2_matmul-gemm", 0);
+        if (backward_out) matmul(ctx, G, W, G_out, (r_t)1, discard ? (r_t)0 : (r_t)1, false, true);
+        ctx.record(name + "1_3_matmul-gemm", 0);
+        ctx.register_timer(name + "1_matmul-gemm", name + "1_0_matmul-gemm", name + "1_3_matmul-gemm");
+    }
+
+    void update(const context ctx, const r_t lr, const r_t weight_decay) {
+        axpby(ctx, G_W, W, -lr, 1 - weight_decay);
+        axpy(ctx, G_b, b, -lr);
+    }
+
+    void adam_update(context ctx, const r_t lr, const r_t beta1, const r_t beta2, const r_t weight_decay, const r_t eps) {
+        if (mW.shape() != W.shape()) {
+            mW = dn_t(W.shape()); vW = dn_t(W.shape()); mb = dn_t(b.shape()); vb = dn_t(b.shape());
+            mW.zero(ctx); vW.zero(ctx); mb.zero(ctx); vb.zero(ctx);
+            step = 0;
+        }
+        step += 1;
+        ctx.record(name + "0_adam-update", 0);
+        adam_step(ctx, fused, W, G_W, mW, vW, b, G_b, mb, vb, lr, beta1, beta2, weight_decay, eps, step);
+        ctx.record(name + "1_adam-update", 0);
+        ctx.register_timer(name + "adam-update", name + "0_adam-update", name + "1_adam-update");
+    }
+
+    auto get_b() { return b; }
+    auto get_W() { return W; }
+    auto get_G_W() { return G_W; }
+    auto get_G_b() { return G_b; }
+};
+
+template <typename r_t>
+class dist_row_linear {
+    using dn_t = dist_row_dn_matrix<r_t>;
+    using rdn_t = repl_dn_matrix<r_t>;
+    std::string name;
+    rdn_t W, G_W, mW, vW, b, G_b, mb, vb, ones;
+    dn_t X;
+    bool backward_out, fused;
+    std::size_t step = 0;
+
+public:
+    dist_row_linear(const dist_context ctx, std::string name, std::size_t in, std::size_t out, bool backward_out = true, bool fused = false)
+        : name(name), W(ctx, in, out), G_W(ctx, in, out), b(ctx, 1, out), G_b(ctx, 1, out), backward_out(backward_out), fused(fused) {
+        W.init(ctx);
+        b.init(ctx, std::sqrt((r_t)1.0 / 3));
+    }
+
+    void setX(dn_t new_X) { X = new_X; }
+
+    void operator()(dist_context ctx, dn_t X, dn_t XW, bool discard = true) {
+        broadcast_rows(ctx, b, XW, discard);
+        ctx.record(name + "0_0_matmul-gemm", 0);
+        matmul(ctx, X, W, XW, (r_t)1, (r_t)1);
+        ctx.record(name + "0_1_matmul-gemm", 0);
+        ctx.register_timer(name + "0_matmul-gemm", name + "0_0_matmul-gemm", name + "0_1_matmul-gemm");
+        this->X = X;
+    }
+
+    void backward(dist_context ctx, dn_t G, dn_t G_out, bool discard = true) {
+        if (ones.size() != ctx.size()) { ones = rdn_t(ctx, 1, G.n() / ctx.size()); ones.fill(ctx, 1); }
+        ctx.record(name + "1_0_matmul-gemm", 0);
+        for (std::size_t i = 0; i < ctx.size(); i++) matmul(ctx[i], ones[i], G[i], G_b[i], (r_t)1, (r_t)0);
+        G_b.allreduce(ctx);
+        ctx.record(name + "1_1_matmul-gemm", 0);
+        matmul(ctx, X, G, G_W, (r_t)1, (r_t)0);                    // per-GPU X_i^T G_i + all-reduce
+        ctx.record(name + "1_2_matmul-gemm", 0);
+        if (backward_out) matmul(ctx, G, W, G_out, (r_t)1, discard ? (r_t)0 : (r_t)1, true);
+        ctx.record(name + "1_3_matmul-gemm", 0);
+        ctx.register_timer(name + "1_matmul-gemm", name + "1_0_matmul-gemm", name + "1_3_matmul-gemm");
+    }
+
+    void adam_update(dist_context ctx, const r_t lr, const r_t beta1, const r_t beta2, const r_t weight_decay, const r_t eps) {
+        if (mW.size() != W.size()) {
+            mW = rdn_t(ctx, W.shape()); vW = rdn_t(ctx, W.shape()); mb = rdn_t(ctx, b.shape()); vb = rdn_t(ctx, b.shape());
+            mW.zero(ctx); vW.zero(ctx); mb.zero(ctx); vb.zero(ctx);
+            step = 0;
+        }
+        step += 1;
+        ctx.record(name + "0_adam-update", 0);
+        for (std::size_t i = 0; i < ctx.size(); i++)
+            adam_step(ctx[i], fused, W[i], G_W[i], mW[i], vW[i], b[i], G_b[i], mb[i], vb[i], lr, beta1, beta2, weight_decay, eps, step);
+        ctx.record(name + "1_adam-update", 0);
+        ctx.register_timer(name + "adam-update", name + "0_adam-update", name + "1_adam-update");
+    }
+
+    auto get_b() { return b; }
+    auto get_W() { return W; }
+    auto get_G_W() { return G_W; }
+    auto get_G_b() { return G_b; }
+};
+
+template <typename x_t, typename v_t, typename r_t>
+class gcn_layer {
+    std::string name;
+    sparse_linear<x_t, v_t, r_t> A;
+    linear<r_t> lin;
+    dn_matrix<r_t> HW;                    // HW_buffer
+    mggcn::device_ptr<r_t> AHW_buffer;
+    dn_matrix<r_t> AHW, G_HW, G_out;      // AHW_buffer / HW_buffer / AHW_buffer
+    bool activation, backward_spmm, fused;
+    dn_matrix<r_t> H;
+
+public:
+    gcn_layer(std::string name, csr_matrix<x_t, v_t, r_t> A, csr_matrix<x_t, v_t, r_t> A_T, std::size_t in, std::size_t out,
+              bool activation, bool residual_layer = false, bool backward_spmm = true,
+              mggcn::device_ptr<r_t> HW_buffer = nullptr, bool fused = false)
+        : name(name), A(name, A, A_T), lin(name, in, out, backward_spmm, fused),
+          HW(A.m(), std::min(in, out), HW_buffer ? HW_buffer : mggcn::device_malloc<r_t>(std::max<std::size_t>(A.m(), A_T.n()) * std::min(in, out))),
+          AHW_buffer(mggcn::device_malloc<r_t>(std::max((std::size_t)A.n() * out, (std::size_t)A_T.n() * in))),
+          AHW(A.n(), out, AHW_buffer), G_HW(A_T.n(), std::min(in, out), HW.shared_buffer()), G_out(A_T.n(), in, AHW_buffer),
+          activation(activation), backward_spmm(backward_spmm), fused(fused) {
+        if (residual_layer) throw std::invalid_argument("residual_layer is never enabled by the reference CLI");
+    }
+
+    auto operator()(context ctx, dn_matrix<r_t> H) {
+        this->H = H;
+        bool act_done = false;
+        if (HW.m() == AHW.m()) {                 // out <= in: GEMM first (reference :439-442)
+            lin(ctx, H, HW);
+            if (fused && activation) { A(ctx, HW, AHW, true, MGGCN_SPMM_LEAKY_RELU); act_done = true; }
+            else A(ctx, HW, AHW);
+        } else {                                  // reference :443-446
+            A(ctx, H, HW);
+            lin(ctx, HW, AHW);
+        }
+        if (activation && !act_done) {
+            ctx.record(name + "0_0_activation", 0);
+            leaky_relu_forward(ctx, AHW, AHW);
+            ctx.record(name + "0_1_activation", 0);
+            ctx.register_timer(name + "0_activation", name + "0_0_activation", name + "0_1_activation");
+        }
+        return AHW;
+    }
+
+    auto backward(context ctx, dn_matrix<r_t> G) {
+        auto T = G;
+        if (activation) {
+            ctx.record(name + "1_0_activation", 0);
+            leaky_relu_backward(ctx, AHW, G, AHW);
+            ctx.record(name + "1_1_activation", 0);
+            ctx.register_timer(name + "1_activation", name + "1_0_activation", name + "1_1_activation");
+            T = AHW;
+        }
+        if (HW.m() == AHW.m()) {
+            auto g = G_HW;
+            if (backward_spmm) A.backward(ctx, T, g); else g = T;
+            lin.backward(ctx, g, G_out);
+            return G_out;
+        }
+        lin.setX(H);
+        lin.backward(ctx, T, G_HW);
+        if (backward_spmm) { A.backward(ctx, G_HW, G_out); return G_out; }
+        return G_HW;
+    }
+
+    void update(const context ctx, const r_t lr, const r_t wd) { lin.update(ctx, lr, wd); }
+    void adam_update(const context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) { lin.adam_update(ctx, lr, b1, b2, wd, eps); }
+    auto b() { return lin.get_b(); }
+    auto W() { return lin.get_W(); }
+    auto GW() { return lin.get_G_W(); }
+    auto Gb() { return lin.get_G_b(); }
+};
+
+template <bool row_partition, typename x_t, typename v_t, typename r_t>
+class dist_gcn_layer {
+    using csr_t = dist_row_csr_matrix<x_t, v_t, r_t>;
+    using dn_t = dist_row_dn_matrix<r_t>;
+    using bufs_t = std::vector<mggcn::device_ptr<r_t>>;
+    std::string name;
+    dist_sparse_linear<row_partition, x_t, v_t, r_t> A;
+    dist_row_linear<r_t> lin;
+    bufs_t AHW_buffer;
+    dn_t HW, AHW, G_HW, G_out;
+    bool activation, backward_spmm, fused;
+    dn_t H;
+
+    static bufs_t alloc(const dist_context &ctx, std::size_t per_gpu) {
+        bufs_t t;
+        for (std::size_t i = 0; i < ctx.size(); i++) { ctx[i].set(); t.push_back(mggcn::device_malloc<r_t>(per_gpu)); }
+        return t;
+    }
+
+public:
+    dist_gcn_layer(const dist_context ctx, std::string name, csr_t A, csr_t A_T, std::size_t in, std::size_t out, bool activation,
+                   bool residual_layer = false, bool backward_spmm = true, bufs_t HW_buffer = {}, bufs_t bcast_buffer = {},
+                   bufs_t bcast_buffer2 = {}, bool fused = false, bool rounds = false)
+        : name(name), A(name, A, A_T, bcast_buffer, bcast_buffer2, rounds), lin(ctx, name, in, out, backward_spmm, fused),
+          AHW_buffer(alloc(ctx, std::max(A.n() * out, A_T.n() * in) / ctx.size())), HW(ctx, A.m(), std::min(in, out), HW_buffer),
+          AHW(ctx, A.n(), out, AHW_buffer), G_HW(ctx, A_T.n(), std::min(in, out), HW_buffer), G_out(ctx, A_T.n(), in, AHW_buffer),
+          activation(activation), backward_spmm(backward_spmm), fused(fused) {
+        if (residual_layer) throw std::invalid_argument("residual_layer is never enabled by the reference CLI");
+    }
+
+    auto operator()(dist_context ctx, dn_t H) {
+        this->H = H;
+        bool act_done = false;
+        if (HW.m() == AHW.m()) {
+            lin(ctx, H, HW);
+            if (fused && activation) { A(ctx, HW, AHW, true, MGGCN_SPMM_LEAKY_RELU); act_done = true; }
+            else A(ctx, HW, AHW);
+        } else {
+            A(ctx, H, HW);
+            lin(ctx, HW, AHW);
+        }
+        if (activation && !act_done) {
+            ctx.record(name + "0_0_activation", 0);
+            leaky_relu_forward(ctx, AHW, AHW);
+            ctx.record(name + "0_1_activation", 0);
+            ctx.register_timer(name + "0_activation", name + "0_0_activation", name + "0_1_activation");
+        }
+        return AHW;
+    }
+
+    auto backward(dist_context ctx, dn_t G) {
+        auto T = G;
+        if (activation) {
+            ctx.record(name + "1_0_activation", 0);
+            leaky_relu_backward(ctx, AHW, G, AHW);
+            ctx.record(name + "1_1_activation", 0);
+            ctx.register_timer(name + "1_activation", name + "1_0_activation", name + "1_1_activation");
+            T = AHW;
+        }
+        if (HW.m() == AHW.m()) {
+            auto g = G_HW;
+            if (backward_spmm) A.backward(ctx, T, g); else g = T;
+            lin.backward(ctx, g, G_out);
+            return G_out;
+        }
+        lin.setX(H);
+        lin.backward(ctx, T, G_HW);
+        if (backward_spmm) { A.backward(ctx, G_HW, G_out); return G_out; }
+        return G_HW;
+    }
+
+    void adam_update(const dist_context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) { lin.adam_update(ctx, lr, b1, b2, wd, eps); }
+    auto b() { return lin.get_b(); }
+    auto W() { return lin.get_W(); }
+    auto GW() { return lin.get_G_W(); }
+    auto Gb() { return lin.get_G_b(); }
+};
+
+// softmax: row max, exp(x - max), row sums by a GEMM with a ones vector, divide (reference :639-676)
+template <typename r_t>
+class softmax {
+    dn_matrix<r_t> ones, H, H_R, maxs;
+    const bool copy;
+
+public:
+    softmax(bool copy = true) : copy(copy) {}
+    auto operator()(const context ctx, dn_matrix<r_t> temp) {
+        if (copy) {
+            if (!H.buffer()) H = dn_matrix<r_t>(temp.n(), temp.m());
+            temp.copy_to(ctx, H);
+        } else {
+            H = temp;
+        }
+        if (!maxs.buffer()) maxs = dn_matrix<r_t>(H.n(), 1);
+        max_rows(ctx, H, maxs);
+        subtract_rows_exp(ctx, H, maxs, H);
+        if (!ones.buffer()) { ones = dn_matrix<r_t>(H.m(), 1); ones.fill(1); }
+        if (!H_R.buffer()) H_R = dn_matrix<r_t>(H.n(), 1);
+        matmul(ctx, H, ones, H_R, (r_t)1, (r_t)0);
+        scale_rows(ctx, H, H_R);
+        return H;
+    }
+};
+
+// One GPU's share of the loss: enqueues everything, leaves {sum|log p_y|, #correct} in
+// sums_device; the caller synchronises and reads (reference :785-818 / :890-930).
+template <typename r_t, typename x_t>
+class loss_kernels {
+    softmax<r_t> softmax_layer;
+    dn_matrix<r_t> G, L, T;
+    dn_matrix<x_t> P;
+    const bool copy, fused;
+    mggcn::device_ptr<r_t> sums_;
+
+public:
+    loss_kernels(bool copy, bool fused) : softmax_layer(copy), copy(copy), fused(fused) {}
+    r_t *sums() const { return sums_.get(); }
+    auto gradient() const { return G; }
+
+    void enqueue(context ctx, dn_matrix<r_t> H, dn_matrix<x_t> Y, std::size_t n_global) {
+        ctx.set();
+        if (!sums_) sums_ = mggcn::device_malloc<r_t>(2);
+        if (fused) {
+            if (copy) {
+                if (!G.buffer()) G = dn_matrix<r_t>(H.n(), H.m());
+                H.copy_to(ctx, G);
+            } else {
+                G = H;
+            }
+            mggcn_memset_zero(sums_.get(), 2 * sizeof(r_t), ctx.stream(0));
+            softmax_xent_fused(ctx, G, Y, (r_t)1 / (r_t)n_global, sums_.get());
+            return;
+        }
+        auto O = softmax_layer(ctx, H);
+        if (!P.buffer()) P = dn_matrix<x_t>(Y.shape());
+        max_row_indices(ctx, O, P);
+        if (!L.buffer()) L = dn_matrix<r_t>(Y.shape());
+        index_log_rows(ctx, O, Y, L);
+        G = O;
+        add_indexed_rows(ctx, G, Y, (r_t)-1);
+        scale_mat(ctx, G, (r_t)1 / (r_t)n_global);
+        if (!T.buffer()) T = dn_matrix<r_t>(Y.shape());
+        is_equal(ctx, Y, P, T);
+        abssum(ctx, L, sums_.get());
+        abssum(ctx, T, sums_.get() + 1);
+    }
+};
+
+template <typename r_t, typename x_t>
+class softmax_cross_entropy_loss {
+    std::string name;
+    loss_kernels<r_t, x_t> k;
+
+public:
+    softmax_cross_entropy_loss(std::string name, bool copy = true, bool fused = false) : name(name), k(copy, fused) {}
+
+    auto operator()(context ctx, dn_matrix<r_t> H, dn_matrix<x_t> Y) {
+        ctx.record(name + "0_loss-layer", 0);
+        k.enqueue(ctx, H, Y, Y.n());
+        ctx.record(name + "1_loss-layer", 0);
+        ctx.register_timer(name + "loss-layer", name + "0_loss-layer", name + "1_loss-layer");
+        ctx.sync();
+        r_t s[2];
+        mggcn::download(s, k.sums(), 2);
+        return std::make_pair(s[0] / H.n(), s[1] / H.n());
+    }
+    auto backward() { return k.gradient(); }
+};
+
+template <typename r_t, typename x_t>
+class dist_row_softmax_cross_entropy_loss {
+    std::string name;
+    std::vector<loss_kernels<r_t, x_t>> ks;
+    const bool copy, fused;
+    dist_row_dn_matrix<r_t> G;
+
+public:
+    dist_row_softmax_cross_entropy_loss(std::string name, bool copy = true, bool fused = false) : name(name), copy(copy), fused(fused) {}
+
+    auto operator()(dist_context ctx, dist_row_dn_matrix<r_t> H, dist_row_dn_matrix<x_t> Y) {
+        while (ks.size() < ctx.size()) ks.emplace_back(copy, fused);
+        ctx.record(name + "0_loss-layer", 0);
+        for (std::size_t i = 0; i < ctx.size(); i++) ks[i].enqueue(ctx[i], H[i], Y[i], Y.n());     // global n (reference :908)
+        ctx.record(name + "1_loss-layer", 0);
+        ctx.register_timer(name + "loss-layer", name + "0_loss-layer", name + "1_loss-layer");
+        ctx.sync();
+        r_t loss = 0, acc = 0;
+        for (std::size_t i = 0; i < ctx.size(); i++) {          // host sum of the per-GPU scalars (reference :929)
+            r_t s[2];
+            ctx[i].set();
+            mggcn::download(s, ks[i].sums(), 2);
+            loss += s[0];
+            acc += s[1];
+        }
+        G = H;                                                   // copy = false: gradient in place, as in dist_gcn
+        if (copy) throw std::invalid_argument("dist loss with copy = true is not used by the reference CLI");
+        return std::make_pair(loss / H.n(), acc / H.n());
+    }
+    auto backward() { return G; }
+};
+
+template <typename x_t, typename v_t, typename r_t>
+class gcn {
+    std::vector<gcn_layer<x_t, v_t, r_t>> layers_;
+    softmax_cross_entropy_loss<r_t, std::int32_t> loss_layer;
+    mggcn::device_ptr<r_t> HW_buffer;
+
+public:
+    // normalises A by column, A_T = A^T, layers get (A_T, A) (reference :946-955)
+    gcn(csr_matrix<x_t, v_t, r_t> A, std::vector<std::size_t> sizes, bool residual_layer = false, bool fused = true)
+        : loss_layer(std::to_string(sizes.size() - 1) + "_", residual_layer, fused) {
+        A.normalize(true);
+        auto A_T = A.transpose();
+        std::size_t max_d = 0;
+        for (std::size_t i = 0; i + 1 < sizes.size(); i++) max_d = std::max(max_d, std::min(sizes[i], sizes[i + 1]));
+        HW_buffer = mggcn::device_malloc<r_t>(std::max<std::size_t>(A.n(), A.m()) * max_d);
+        for (std::size_t i = 1; i < sizes.size(); i++)
+            layers_.emplace_back(std::to_string(i - 1) + "_", A_T, A, sizes[i - 1], sizes[i], i + 1 < sizes.size(), residual_layer,
+                                 i != 1, HW_buffer, fused);
+    }
+
+    // test constructor with given weights (reference :957-963)
+    gcn(csr_matrix<x_t, v_t, r_t> A, std::vector<std::size_t> sizes, std::vector<std::pair<std::vector<r_t>, std::vector<r_t>>> weights)
+        : gcn(A, sizes) {
+        for (std::size_t i = 0; i < layers_.size(); i++) {
+            layers_[i].W().init(weights[i].first);
+            layers_[i].b().init(weights[i].second);
+        }
+    }
+
+    auto operator()(const context ctx, dn_matrix<r_t> H) {
+        for (auto &layer : layers_) H = layer(ctx, H);
+        return H;
+    }
+    auto train_forward(const context ctx, dn_matrix<r_t> H, dn_matrix<std::int32_t> Y) {
+        H = operator()(ctx, H);
+        return loss_layer(ctx, H, Y);
+    }
+    void backward(const context ctx) {
+        auto G = loss_layer.backward();
+        for (auto l = layers_.rbegin(); l != layers_.rend(); l++) G = l->backward(ctx, G);
+    }
+    void update(const context ctx, const r_t lr, const r_t wd) { for (auto &l : layers_) l.update(ctx, lr, wd); }
+    void adam_update(const context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) {
+        for (auto &l : layers_) l.adam_update(ctx, lr, b1, b2, wd, eps);
+    }
+    auto &layers() { return layers_; }
+};
+
+template <bool row_partition, typename x_t, typename v_t, typename r_t>
+class dist_gcn {
+    using csr_t = dist_row_csr_matrix<x_t, v_t, r_t>;
+    using dn_t = dist_row_dn_matrix<r_t>;
+    using idn_t = dist_row_dn_matrix<std::int32_t>;
+    using bufs_t = std::vector<mggcn::device_ptr<r_t>>;
+    std::vector<dist_gcn_layer<row_partition, x_t, v_t, r_t>> layers_;
+    dist_row_softmax_cross_entropy_loss<r_t, std::int32_t> loss_layer;
+    bufs_t HW_buffer, bcast_buffer, bcast_buffer2;
+
+public:
+    // per-GPU HW_buffer + receive buffers shared by all layers (reference :1016-1021).  The
+    // all-gather schedule keeps the whole gathered B resident per GPU (n x max_d floats).
+    dist_gcn(const dist_context ctx, csr_t A, csr_t A_T, std::vector<std::size_t> sizes, bool residual_layer = false,
+             bool fused = true, bool rounds = false)
+        : loss_layer(std::to_string(sizes.size() - 1) + "_", residual_layer, fused) {
+        std::size_t max_d = 0;
+        for (std::size_t i = 0; i + 1 < sizes.size(); i++) max_d = std::max(max_d, std::min(sizes[i], sizes[i + 1]));
+        const std::size_t nmax = std::max(A.n(), A.m()), shard = nmax * max_d / ctx.size();
+        for (std::size_t i = 0; i < ctx.size(); i++) {
+            ctx[i].set();
+            HW_buffer.push_back(mggcn::device_malloc<r_t>(shard));
+            bcast_buffer.push_back(mggcn::device_malloc<r_t>(rounds ? shard : nmax * max_d));
+            bcast_buffer2.push_back(mggcn::device_malloc<r_t>(shard));
+        }
+        for (std::size_t i = 1; i < sizes.size(); i++)
+            layers_.emplace_back(ctx, std::to_string(i - 1) + "_", A_T, A, sizes[i - 1], sizes[i], i + 1 < sizes.size(), residual_layer,
+                                 i != 1, HW_buffer, bcast_buffer, bcast_buffer2, fused, rounds);
+    }
+
+    auto operator()(const dist_context ctx, dn_t H) {
+        for (auto &layer : layers_) H = layer(ctx, H);
+        return H;
+    }
+    auto train_forward(const dist_context ctx, dn_t H, idn_t Y) {
+        H = operator()(ctx, H);
+        return loss_layer(ctx, H, Y);
+    }
+    void backward(const dist_context ctx) {
+        auto G = loss_layer.backward();
+        for (auto l = layers_.rbegin(); l != layers_.rend(); l++) G = l->backward(ctx, G);
+    }
+    void adam_update(const dist_context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) {
+        for (auto &l : layers_) l.adam_update(ctx, lr, b1, b2, wd, eps);
+    }
+    auto &layers() { return layers_; }
+};

@@ -1,0 +1,169 @@
+// main.cpp -- the `mg_gcn` command line of the reference (src/main.cpp) on the HIP engine.
+//
+//   mg_gcn [-h] [-P gpus] [-R 0/1] [-E epochs] [-S x] [-N] train <dir> <k> <h1> ... <hk>
+//
+// Same flag grammar (getopt "h?P:R:E:S:N", src/main.cpp:58), same dataset files
+// (graph.bin / features.bin / labels.bin / sets.bin, :82-85), same stderr lines
+// ("n nnz", "num_labels = ", "feature size = ", then per epoch "e loss acc seconds", :87-91,
+// :130, :167), same per-epoch timer dump "csvs/<name>_<sizes>_<P>.csv" (:100-111, :131, :168),
+// same hyper-parameters (Adam 1e-2 / 0.9 / 0.999 / 5e-4 / 1e-8, :126).  Like the reference,
+// P > 1 trains only with -R 1 (row partition); classes are padded to a multiple of P (:135).
+// Environment: MGGCN_DIST_MODE=rounds selects the reference's broadcast pipeline instead of
+// the all-gather exchange; MGGCN_FUSED=0 replays the reference's launch sequence.
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "gcn.hpp"
+
+using x_t = unsigned;
+using v_t = unsigned;
+using r_t = float;
+
+class arg_error : public std::runtime_error {
+public:
+    template <typename T>
+    arg_error(T t) : std::runtime_error(t) {}
+};
+
+static int usage_(char *prog) {
+    std::cout << "Usage: " << prog << " [-h] [-P gpus] [-R 0/1] [-E epochs] [-S x] [-N] train <dir> <k> <h1..hk>" << std::endl;
+    return 0;
+}
+
+static int help_() {
+    std::cout << "\nMG-GCN full-graph multi-GPU GCN training, MI355X (gfx950) engine.\n\n"
+                 "Options:\n"
+                 "    -P : number of GPUs\n"
+                 "    -R : enable the 1D row partition (required for -P > 1)\n"
+                 "    -E : number of epochs (default 20)\n"
+                 "    -S : disable communication/computation overlap\n"
+                 "Arguments:\n"
+                 "    train <dir> <k> <h1> ... <hk> : dataset directory, number of hidden layers and their widths\n";
+    return EXIT_SUCCESS;
+}
+
+static bool env_is(const char *name, const char *value) {
+    const char *s = std::getenv(name);
+    return s && std::string(s) == value;
+}
+
+int main_(int argc, char **argv) {
+    opterr = 0;
+    std::size_t P = 1, row_partition = 0, num_epochs = 20;
+    bool overlap = true;
+    while (optind < argc) {
+        int c = getopt(argc, argv, "h?P:R:E:S:N");
+        if (c == -1) break;
+        switch (c) {
+            case '?': return usage_(argv[0]);
+            case 'h': usage_(argv[0]); return help_();
+            case 'P': P = std::stoull(optarg); break;
+            case 'R': row_partition = std::stoull(optarg); break;
+            case 'E': num_epochs = std::stoull(optarg); break;
+            case 'S': overlap = false; break;
+            case 'N': overlap = true; break;                       // no_wait: parsed, unused (reference :67)
+            default: throw arg_error("Unknown argument.");
+        }
+    }
+    const bool fused = !env_is("MGGCN_FUSED", "0");
+    const bool rounds = env_is("MGGCN_DIST_MODE", "rounds");
+
+    while (optind < argc && argv[optind] != nullptr) {
+        const std::string command = argv[optind++];
+        if (command.rfind("train", 0) != 0) throw arg_error("Unknown command.");
+        if (optind >= argc) throw arg_error("train needs a dataset directory.");
+        const std::filesystem::path dir = argv[optind++];
+        if ((int)mggcn_device_count() < (int)std::max<std::size_t>(P, 1)) throw arg_error("not enough GPUs visible for -P");
+
+        mggcn_set_device(0);
+        csr_matrix<x_t, v_t, r_t> A(dir / "graph.bin");
+        dn_matrix<r_t> X(dir / "features.bin");
+        dn_matrix<std::int32_t> Y(dir / "labels.bin");
+        dn_matrix<std::int32_t> S(dir / "sets.bin");               // loaded, never used (reference :85)
+        (void)S;
+        std::cerr << A.n() << ' ' << A.nnz() << std::endl;
+        const auto labels = Y.to_host();
+        const auto num_labels = 1 + *std::max_element(labels.begin(), labels.end());
+        std::cerr << "num_labels = " << num_labels << std::endl;
+        std::cerr << "feature size = " << X.m() << std::endl;
+
+        if (optind >= argc) throw arg_error("train needs the number of hidden layers.");
+        const int num_sizes = std::stoi(argv[optind++]);
+        std::vector<std::size_t> sizes{X.m()};
+        for (int i = 0; i < num_sizes; i++) {
+            if (optind >= argc) throw arg_error("missing hidden layer width.");
+            sizes.push_back(std::stoull(argv[optind++]));
+        }
+        sizes.push_back((std::size_t)num_labels);
+
+        // csvs/<[permuted_]name>_<sizes>_<P>.csv (reference :100-111)
+        std::string filename;
+        bool permuted = false;
+        for (const auto &part : (dir / "graph.bin").parent_path()) {
+            if (part == "permuted") permuted = true;
+            else if (!part.empty() && part != "/" && part != ".") filename = (permuted ? std::string("permuted_") : std::string("")) + part.string();
+        }
+        for (auto s : sizes) filename += "_" + std::to_string(s);
+        std::filesystem::create_directories("csvs");
+        std::ofstream of("csvs/" + filename + "_" + std::to_string(P) + ".csv");
+
+        if (P <= 1) {
+            auto ctx = context(0);
+            gcn<x_t, v_t, r_t> G(A, sizes, false, fused);
+            ctx.sync();
+            ctx.record("training-start", 0);
+            for (std::size_t e = 0; e < num_epochs; e++) {
+                const auto start = std::chrono::system_clock::now();
+                auto [loss, acc] = G.train_forward(ctx, X, Y);
+                G.backward(ctx);
+                G.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8);
+                ctx.sync();
+                const auto duration = std::chrono::duration<double>{std::chrono::system_clock::now() - start}.count();
+                std::cerr << e << ' ' << loss << ' ' << acc << ' ' << duration << std::endl;
+                ctx.dump_timers(of, std::to_string(e) + "_0_");
+            }
+        } else if (row_partition) {
+            sizes.back() = (sizes.back() + P - 1) / P * P;          // reference :135
+            auto ctx = dist_context(P, overlap);
+            std::vector<v_t> p(P + 1);
+            for (std::size_t i = 1; i < p.size(); i++) p[i] = (v_t)(i * A.n() / P);
+            A.normalize(true);
+            auto A_T = A.transpose();
+            dist_row_dn_matrix<std::int32_t> Yd(ctx, Y);
+            dist_row_csr_matrix<x_t, v_t, r_t> Ad(ctx, A, p, p);
+            dist_row_csr_matrix<x_t, v_t, r_t> A_Td(ctx, A_T, p, p);
+            dist_gcn<true, x_t, v_t, r_t> G(ctx, Ad, A_Td, sizes, false, fused, rounds);
+            dist_row_dn_matrix<r_t> Xd(ctx, X);
+            ctx.sync();
+            ctx.record("training-start", 0);
+            for (std::size_t e = 0; e < num_epochs; e++) {
+                const auto start = std::chrono::system_clock::now();
+                auto [loss, acc] = G.train_forward(ctx, Xd, Yd);
+                G.backward(ctx);
+                G.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8);
+                ctx.sync();
+                const auto duration = std::chrono::duration<double>{std::chrono::system_clock::now() - start}.count();
+                std::cerr << e << ' ' << loss << ' ' << acc << ' ' << duration << "\n";
+                ctx.dump_timers(of, std::to_string(e) + "_");
+            }
+        }
+        // P > 1 without -R 1 trains nothing, exactly like the reference (:145, :171-189)
+    }
+    return EXIT_SUCCESS;
+}
+
+int main(int argc, char **argv) {
+    try {
+        return main_(argc, argv);
+    } catch (const std::exception &e) {
+        std::cerr << "Error: uncaught exception: '" << e.what() << "' Aborting." << std::endl;
+        std::exit(EXIT_FAILURE);
+    }
+}

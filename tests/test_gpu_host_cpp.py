@@ -1,0 +1,65 @@
+"""The C++17 host layer (mg-gcn_amd/host: the reference's class names over the C ABI) on the
+GPU: its restated reference tests and the `mg_gcn` CLI, whose per-epoch losses are checked
+against the CPU oracle on a dataset written in the reference's on-disk format."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "mg-gcn_amd", "bin")
+
+
+def _run(args, cwd=None, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run(args, cwd=cwd, env=e, capture_output=True, text=True, timeout=600)
+
+
+def test_cpp_reference_tests_pass(golden_dir):
+    for exe, arg in (("test_matrix", golden_dir), ("test_gcn", os.path.join(golden_dir, "toyB"))):
+        r = _run([os.path.join(BIN, exe), arg])
+        assert r.returncode == 0, (exe, r.stdout, r.stderr)
+        assert "TEST FAILED" not in r.stdout and r.stdout.count("TEST PASSED") >= 6, r.stdout
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_cli_matches_oracle(pkg, oracle, tmp_path, fused):
+    n, F, C = 1024, 24, 6
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, n * 20, 900, seed=7)
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((n, F), dtype=np.float32)
+    Y = rng.integers(0, C, size=(n, 1)).astype(np.int32)
+    Y[0, 0] = C - 1
+    d = tmp_path / "permuted" / "synth"
+    pkg.datasets.write_dataset(str(d), ip, ix, dv, X, Y)
+    r = _run([os.path.join(BIN, "mg_gcn"), "-E", "3", "train", str(d), "2", "16", "16"], cwd=str(tmp_path),
+             env={"MGGCN_FUSED": fused})
+    assert r.returncode == 0, r.stderr
+    lines = r.stderr.strip().splitlines()
+    assert lines[0] == f"{n} {n * 20}" and lines[1] == f"num_labels = {C}" and lines[2] == f"feature size = {F}"
+    got = [tuple(float(x) for x in ln.split()) for ln in lines[3:6]]
+    O = oracle.Gcn(oracle.Csr(ip, ix, dv, n), [F, 16, 16, C])
+    want = []
+    for _ in range(3):
+        want.append(O.train_forward(X, Y)); O.backward(); O.adam_update()
+    assert [int(g[0]) for g in got] == [0, 1, 2]
+    assert abs(got[0][1] - want[0][0]) <= 1e-4 * want[0][0]            # identical inputs at epoch 0
+    for g, w in zip(got, want):
+        assert abs(g[1] - w[0]) <= 2e-3 * w[0] and abs(g[2] - w[1]) <= 0.02    # later epochs: Adam drift, see test_gpu_gcn
+    csv = tmp_path / "csvs" / f"permuted_synth_{F}_16_16_{C}_1.csv"       # reference file name scheme (main.cpp:100-111)
+    text = csv.read_text()
+    assert re.search(r"^0_0_0_0_matmul-spmm:", text, re.M) and re.search(r"^2_0_2_loss-layer:", text, re.M)
+
+
+def test_cli_errors_like_the_reference(tmp_path):
+    r = _run([os.path.join(BIN, "mg_gcn"), "bogus"], cwd=str(tmp_path))
+    assert r.returncode == 1 and "uncaught exception: 'Unknown command.'" in r.stderr      # main.cpp:193, :198-206
+    r = _run([os.path.join(BIN, "mg_gcn"), "train", str(tmp_path / "nope"), "1", "8"], cwd=str(tmp_path))
+    assert r.returncode == 1 and "Aborting" in r.stderr
+    r = _run([os.path.join(BIN, "mg_gcn"), "-h"], cwd=str(tmp_path))
+    assert r.returncode == 0 and "Usage" in r.stdout
