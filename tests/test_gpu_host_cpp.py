@@ -53,7 +53,7 @@ def test_cli_matches_oracle(pkg, oracle, tmp_path, fused):
         assert abs(g[1] - w[0]) <= 2e-3 * w[0] and abs(g[2] - w[1]) <= 0.02    # later epochs: Adam drift, see test_gpu_gcn
     csv = tmp_path / "csvs" / f"permuted_synth_{F}_16_16_{C}_1.csv"       # reference file name scheme (main.cpp:100-111)
     text = csv.read_text()
-    assert re.search(r"^0_0_0_0_matmul-spmm:", text, re.M) and re.search(r"^2_0_2_loss-layer:", text, re.M)
+    assert re.search(r"^0_0_0_0_matmul-spmm:", text, re.M) and re.search(r"^2_0_3_loss-layer:", text, re.M)
 
 
 def test_cli_errors_like_the_reference(tmp_path):
