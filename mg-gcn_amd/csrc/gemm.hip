@@ -183,18 +183,76 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(
         }
 }
 
-// C = alpha * sum_z slab[z] + beta * C, z in increasing order
+// C = alpha * sum_z slab[z] + beta * C.  256 threads = 32 outputs x 8 split-groups: group g adds
+// slabs g, g+8, g+16, ... (independent loads, unrolled), the 8 group sums are folded through
+// LDS in group order -> a fixed summation tree, bitwise reproducible.
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float *__restrict__ slab,
                                                                  uint32_t splits, uint32_t M, uint32_t N,
                                                                  float alpha, float beta,
                                                                  float *__restrict__ C, size_t ldc) {
-    const size_t total = (size_t)M * N;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    __shared__ float part[8][33];
+    const uint32_t total = M * N;                    // < 2^32: checked by the launcher
+    const uint32_t lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    for (uint32_t base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
+        const uint32_t i = base + lane;
         float s = 0.f;
-        for (uint32_t z = 0; z < splits; z++) s += slab[(size_t)z * total + i];
-        float *cp = C + (i / N) * ldc + (i % N);
-        *cp = beta == 0.f ? alpha * s : fmaf(beta, *cp, alpha * s);
+        if (i < total) {
+#pragma unroll 4
+            for (uint32_t z = grp; z < splits; z += 8) s += slab[(size_t)z * total + i];
+        }
+        part[grp][lane] = s;
+        __syncthreads();
+        if (grp == 0 && i < total) {
+            float t = part[0][lane];
+#pragma unroll
+            for (int g = 1; g < 8; g++) t += part[g][lane];
+            float *cp = C + (size_t)(i / N) * ldc + (i % N);
+            *cp = beta == 0.f ? alpha * t : fmaf(beta, *cp, alpha * t);
+        }
+        __syncthreads();
+    }
+}
+
+// Very thin op(A) (M <= 4 rows, not transposed): G_b = 1^T G (reference src/gcn.hpp:131) and
+// friends.  An MFMA tile would waste 124 of its 128 rows; this is a plain HBM stream of B:
+// thread (tx, ty) owns columns {n0+tx, n0+tx+64} and the k's congruent to ty (mod 4) of the
+// block's K-chunk; the four ty partials are folded through LDS in order and the chunk's
+// [M x N] partial goes to the split-K slab.
+template <int MROWS>
+__global__ __launch_bounds__(256) void gemm_thin_kernel(uint32_t N, uint32_t K, const float *__restrict__ A,
+                                                        size_t lda, const float *__restrict__ B, size_t ldb,
+                                                        float *__restrict__ slab, uint32_t k_chunk, uint32_t M) {
+    __shared__ float red[4][MROWS][128];
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const uint32_t n0 = blockIdx.x * 128;
+    const uint32_t c0 = n0 + tx, c1 = n0 + tx + 64;
+    const uint32_t k_begin = blockIdx.y * k_chunk, k_end = min(K, k_begin + k_chunk);
+    float acc0[MROWS], acc1[MROWS];
+#pragma unroll
+    for (int m = 0; m < MROWS; m++) { acc0[m] = 0.f; acc1[m] = 0.f; }
+    for (uint32_t k = k_begin + ty; k < k_end; k += 4) {
+        const float b0 = c0 < N ? B[(size_t)k * ldb + c0] : 0.f;
+        const float b1 = c1 < N ? B[(size_t)k * ldb + c1] : 0.f;
+#pragma unroll
+        for (int m = 0; m < MROWS; m++) {
+            const float a = (uint32_t)m < M ? A[(size_t)m * lda + k] : 0.f;
+            acc0[m] = fmaf(a, b0, acc0[m]);
+            acc1[m] = fmaf(a, b1, acc1[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MROWS; m++) { red[ty][m][tx] = acc0[m]; red[ty][m][tx + 64] = acc1[m]; }
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+        for (int m = 0; m < MROWS; m++) {
+            if ((uint32_t)m >= M) break;
+            const float s0 = ((red[0][m][tx] + red[1][m][tx]) + red[2][m][tx]) + red[3][m][tx];
+            const float s1 = ((red[0][m][tx + 64] + red[1][m][tx + 64]) + red[2][m][tx + 64]) + red[3][m][tx + 64];
+            float *out = slab + ((size_t)blockIdx.y * M + m) * N;
+            if (c0 < N) out[c0] = s0;
+            if (c1 < N) out[c1] = s1;
+        }
     }
 }
 
@@ -213,6 +271,19 @@ struct Split {
     uint32_t splits;
     uint32_t k_chunk;   // multiple of BK
 };
+
+constexpr uint32_t kThinRows = 4;
+
+inline bool use_thin(int trans_a, int trans_b, uint32_t M, uint32_t K) {
+    return !trans_a && !trans_b && M <= kThinRows && K >= 4096;
+}
+
+// thin path: ~1024 K-chunks of a multiple of 64
+Split choose_split_thin(uint32_t K) {
+    uint32_t chunk = (K + 1023) / 1024;
+    chunk = (chunk + 63) / 64 * 64;
+    return {(K + chunk - 1) / chunk, chunk};
+}
 
 // Tall reductions: give every CU about two tiles' worth of K-slices.
 Split choose_split(uint32_t M, uint32_t N, uint32_t K) {
@@ -235,6 +306,7 @@ Split choose_split(uint32_t M, uint32_t N, uint32_t K) {
 MGGCN_API size_t mggcn_gemm_workspace_bytes(int trans_a, int trans_b, uint32_t M, uint32_t N, uint32_t K) {
     (void)trans_a; (void)trans_b;
     if (!M || !N || !K) return 0;
+    if (use_thin(trans_a, trans_b, M, K)) return (size_t)choose_split_thin(K).splits * M * N * sizeof(float);
     const Split s = choose_split(M, N, K);
     return s.splits > 1 ? (size_t)s.splits * M * N * sizeof(float) : 0;
 }
@@ -255,6 +327,20 @@ MGGCN_API void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, u
     MGGCN_REQUIRE(A != nullptr && B != nullptr, "null operand");
     MGGCN_REQUIRE(lda >= (trans_a ? M : K), "lda smaller than the stored row of A");
     MGGCN_REQUIRE(ldb >= (trans_b ? K : N), "ldb smaller than the stored row of B");
+    MGGCN_REQUIRE((uint64_t)M * N < (1ull << 31), "output too large");
+    if (use_thin(trans_a, trans_b, M, K)) {
+        const Split sp = choose_split_thin(K);
+        MGGCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)sp.splits * M * N * sizeof(float),
+                      "thin GEMM needs the workspace reported by mggcn_gemm_workspace_bytes");
+        float *slab = static_cast<float *>(workspace);
+        hipLaunchKernelGGL((gemm_thin_kernel<kThinRows>), dim3((N + 127) / 128, sp.splits), dim3(256), 0, st, N, K, A,
+                           lda, B, ldb, slab, sp.k_chunk, M);
+        MGGCN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(std::min<unsigned>((M * N + 31) / 32, 2048u)), dim3(256), 0,
+                           st, slab, sp.splits, M, N, alpha, beta, C, ldc);
+        MGGCN_CHECK_LAUNCH();
+        return;
+    }
     const Split sp = choose_split(M, N, K);
     float *slab = nullptr;
     if (sp.splits > 1) {
@@ -285,8 +371,8 @@ MGGCN_API void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, u
 #undef MGGCN_GEMM_LAUNCH
     MGGCN_CHECK_LAUNCH();
     if (sp.splits > 1) {
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(stream_grid((size_t)M * N)), dim3(256), 0, st, slab,
-                           sp.splits, M, N, alpha, beta, C, ldc);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(std::min<unsigned>((M * N + 31) / 32, 2048u)), dim3(256), 0,
+                           st, slab, sp.splits, M, N, alpha, beta, C, ldc);
         MGGCN_CHECK_LAUNCH();
     }
 }
