@@ -258,7 +258,9 @@ struct mggcn_spmm_plan {
     float *d_partial = nullptr;
     size_t bytes = 0;
     int device = 0;
-    SweepPlan *sweep = nullptr;     // column-panel sweep form (large matrices; spmm_sweep.hip)
+    // column-panel sweep form (large matrices; spmm_sweep.hip): one plan per column SLICE of
+    // the matrix, run back to back with beta accumulation (see mggcn_spmm_plan_create)
+    std::vector<SweepPlan *> sweeps;
 };
 
 MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,
@@ -315,13 +317,48 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_co
     plan->bytes = ib + sb + pb;
     const char *algo = std::getenv("MGGCN_SPMM_ALGO");
     if (host_indices && host_values && !(algo && std::string(algo) == "rowsplit"))
-        plan->sweep = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d);
+    {
+        // Column slices: the sweep keeps the active part of B in L2 only while the waves stay
+        // within a few MiB of each other; their drift grows with the length of the sweep
+        // (measured: a 32 MiB extent runs at the in-L2 rate, the full 114 MiB Reddit extent 25 %
+        // slower).  So B is cut into slices of <= MGGCN_SPMM_SLICE_MIB (at 512-byte rows) and
+        // C = beta C + alpha sum_s A[:, slice s] B is evaluated slice after slice: every launch
+        // boundary re-synchronises the chip.  Costs one extra read+write of C per extra slice.
+        const uint64_t slice_rows = std::max<uint64_t>(
+            64, env_u32("MGGCN_SPMM_SLICE_ROWS", env_u32("MGGCN_SPMM_SLICE_MIB", 32u) * 2048u));   // tests set ROWS
+        const uint32_t S = (uint32_t)std::max<uint64_t>(1, ((uint64_t)n_cols + slice_rows - 1) / slice_rows);
+        if (S <= 1) {
+            if (SweepPlan *sp = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d))
+                plan->sweeps.push_back(sp);
+        } else {
+            const uint32_t width = (n_cols + S - 1) / S;
+            std::vector<uint32_t> ip((size_t)n_rows + 1), ix;
+            std::vector<float> vv;
+            bool ok = true;
+            for (uint32_t sidx = 0; sidx < S && ok; sidx++) {
+                const uint32_t lo = sidx * width, hi = std::min<uint64_t>(n_cols, (uint64_t)lo + width);
+                ix.clear(); vv.clear();
+                ip[0] = 0;
+                for (uint32_t r = 0; r < n_rows; r++) {
+                    for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++)
+                        if (host_indices[e] >= lo && host_indices[e] < hi) { ix.push_back(host_indices[e]); vv.push_back(host_values[e]); }
+                    ip[r + 1] = (uint32_t)ix.size();
+                }
+                SweepPlan *sp = sweep_plan_build(n_rows, n_cols, ip.data(), ix.data(), vv.data(), max_d, /*force=*/sidx > 0);
+                if (sp) plan->sweeps.push_back(sp); else ok = false;
+            }
+            if (!ok) {                                   // all or nothing: the slices must cover A
+                for (auto *sp : plan->sweeps) sweep_plan_destroy(sp);
+                plan->sweeps.clear();
+            }
+        }
+    }
     return plan;
 }
 
 MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {
     if (!plan) return;
-    sweep_plan_destroy(plan->sweep);
+    for (auto *sp : plan->sweeps) sweep_plan_destroy(sp);
     if (plan->d_items) MGGCN_CHECK_HIP(hipFree(plan->d_items));
     if (plan->d_split) MGGCN_CHECK_HIP(hipFree(plan->d_split));
     if (plan->d_partial) MGGCN_CHECK_HIP(hipFree(plan->d_partial));
@@ -331,10 +368,14 @@ MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {
 MGGCN_API uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan) { return plan->n_items; }
 MGGCN_API uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan) { return plan->n_split_rows; }
 MGGCN_API size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan) {
-    return plan->bytes + sweep_plan_bytes(plan->sweep);
+    size_t b = plan->bytes;
+    for (auto *sp : plan->sweeps) b += sweep_plan_bytes(sp);
+    return b;
 }
 MGGCN_API uint32_t mggcn_spmm_plan_num_sweep_tasks(const mggcn_spmm_plan *plan) {
-    return sweep_plan_tasks(plan->sweep);
+    uint32_t t = 0;
+    for (auto *sp : plan->sweeps) t += sweep_plan_tasks(sp);
+    return t;
 }
 
 namespace {
@@ -384,8 +425,11 @@ MGGCN_API void mggcn_spmm_csr_f32(mggcn_stream_t stream, const mggcn_spmm_plan *
     if (plan) {
         MGGCN_REQUIRE(plan->n_rows == n_rows && plan->n_cols == n_cols, "plan built for another matrix");
         MGGCN_REQUIRE(d <= plan->max_d || plan->n_slots == 0, "feature width exceeds the plan's max_d");
-        if (plan->sweep && sweep_supports(plan->sweep, d, ldb, ldc, B, C)) {
-            sweep_launch(st, plan->sweep, B, ldb, C, ldc, d, alpha, beta, flags, slope);
+        if (!plan->sweeps.empty() && sweep_supports(plan->sweeps[0], d, ldb, ldc, B, C)) {
+            const size_t S = plan->sweeps.size();
+            for (size_t k = 0; k < S; k++)       // beta only once, the fused activation only on the full sum
+                sweep_launch(st, plan->sweeps[k], B, ldb, C, ldc, d, alpha, k == 0 ? beta : 1.f,
+                             k + 1 == S ? flags : 0u, slope);
             return;
         }
         launch_main<true>(st, plan, plan->n_items, indptr, indices, values, B, ldb, C, ldc, d, alpha,

@@ -8,8 +8,9 @@ struct SweepPlan;   // opaque to spmm.hip
 
 // Builds the panel-swept entry stream for one CSR matrix (host arrays) and uploads it.
 // Returns nullptr when the matrix is not worth sweeping (tiny).
+// force: build even below the size threshold (later column slices of a sliced matrix)
 SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
-                            const uint32_t *indices, const float *values, uint32_t max_d);
+                            const uint32_t *indices, const float *values, uint32_t max_d, bool force = false);
 void sweep_plan_destroy(SweepPlan *p);
 size_t sweep_plan_bytes(const SweepPlan *p);
 uint32_t sweep_plan_tasks(const SweepPlan *p);

@@ -40,6 +40,9 @@ __device__ f32x2_t mggcn_buffer_load_v2f32(__amdgpu_buffer_rsrc_t rsrc, int voff
     __asm("llvm.amdgcn.raw.ptr.buffer.load.v2f32");
 __device__ float mggcn_buffer_load_f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.ptr.buffer.load.f32");
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ f32x4_t mggcn_buffer_load_v4f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v4f32");
 
 namespace {
 
@@ -241,6 +244,112 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// float4 "pair" form (d % 4 == 0, 16-byte aligned rows): the 8-byte gathers of the kernel
+// above top out at ~17.5 TB/s even with every access hitting L2 (8-B accesses run at
+// 0.54-0.70x the 16-B rate, MI355X_MICROARCH.md), the 16-byte row-split kernel reaches 22.
+// Here a 128-wide row is 32 lanes x float4 and ONE buffer_load_dwordx4 fetches the two rows
+// of an entry pair, one per half-wave (the plan made every run even and ordered each pair by
+// column, so the upper half's extra offset is non-negative).  Both halves accumulate partial
+// sums of the SAME output row (the run's row is still wave-uniform -> index-mode fold); the
+// halves are added once per task at write-out.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair_kernel(
+    const SweepTask *__restrict__ tasks, uint32_t task0, uint32_t n_launch,
+    const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
+    const float *__restrict__ B, uint32_t b_bytes, uint32_t row_bytes, float *__restrict__ C, size_t ldc,
+    float *__restrict__ partial, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wib = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
+    const uint32_t local = blockIdx.x * kWavesPerBlock + wib;
+    if (local >= n_launch) return;                    // no barriers: waves are independent
+    const uint32_t t = task0 + local;
+    const SweepTask task = tasks[t];
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, b_bytes, 0x00020000);
+    const uint32_t sub = lane & 31;
+    const uint32_t hmask = (lane & 32) ? 0xFFFFFFFFu : 0u;     // upper half-wave takes the pair's 2nd entry
+
+    for (uint32_t col0 = 0; col0 < d; col0 += 128) {
+        const uint32_t col = col0 + sub * 4;
+        const bool active = col < d;
+        const uint32_t lane_off = (active ? col : 0) * 4u;
+        f32x16 p0, p1, p2, p3;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { p0[r] = 0.f; p1[r] = 0.f; p2[r] = 0.f; p3[r] = 0.f; }
+        uint32_t cur_row = 0;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+
+        if (task.beg < task.end) {
+            EntryBatch cur = load_batch(entries, task.beg);
+            for (uint32_t e = task.beg; e < task.end; e += 8) {
+                const uint32_t e_next = e + 8 < task.end ? e + 8 : e;
+                const EntryBatch nxt = load_batch(entries, e_next);
+                f32x4_t b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t off_a = (cur.pk(2 * u) & kColMask) * row_bytes;
+                    const uint32_t off_b = (cur.pk(2 * u + 1) & kColMask) * row_bytes;     // >= off_a
+                    const uint32_t voff = lane_off + ((off_b - off_a) & hmask);
+                    b[u] = mggcn_buffer_load_v4f32(rsrc, (int)voff, (int)off_a, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t pk = cur.pk(2 * u);
+                    if (pk & kRunFlag) {                                   // first pair of a (panel,row) run
+                        p0[cur_row] += acc[0];
+                        p1[cur_row] += acc[1];
+                        p2[cur_row] += acc[2];
+                        p3[cur_row] += acc[3];
+                        acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                        cur_row = (pk >> kColBits) & (kRW - 1);
+                    }
+                    const uint32_t va = __builtin_bit_cast(uint32_t, cur.val(2 * u));
+                    const uint32_t vb = __builtin_bit_cast(uint32_t, cur.val(2 * u + 1));
+                    const float v = __builtin_bit_cast(float, (va & ~hmask) | (vb & hmask));
+                    acc[0] = fmaf(v, b[u][0], acc[0]);
+                    acc[1] = fmaf(v, b[u][1], acc[1]);
+                    acc[2] = fmaf(v, b[u][2], acc[2]);
+                    acc[3] = fmaf(v, b[u][3], acc[3]);
+                }
+                cur = nxt;
+            }
+        }
+        p0[cur_row] += acc[0];
+        p1[cur_row] += acc[1];
+        p2[cur_row] += acc[2];
+        p3[cur_row] += acc[3];
+
+        // add the two half-waves' partial rows, then the common epilogue from lanes 0..31
+        auto emit = [&](uint32_t r, float x0, float x1, float x2, float x3) {
+            x0 += __shfl_xor(x0, 32); x1 += __shfl_xor(x1, 32);
+            x2 += __shfl_xor(x2, 32); x3 += __shfl_xor(x3, 32);
+            if (r >= task.n_rows || !active || hmask) return;
+            const uint32_t dst = task_rows[(size_t)t * kRW + r];
+            float4 s = make_float4(x0, x1, x2, x3);
+            if (dst & kSlotFlag) {
+                *reinterpret_cast<float4 *>(partial + (size_t)(dst & ~kSlotFlag) * d + col) = s;
+                return;
+            }
+            float4 *cp = reinterpret_cast<float4 *>(C + (size_t)dst * ldc + col);
+            s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
+            if (beta != 0.f) {
+                const float4 c0 = *cp;
+                s.x = fmaf(beta, c0.x, s.x); s.y = fmaf(beta, c0.y, s.y);
+                s.z = fmaf(beta, c0.z, s.z); s.w = fmaf(beta, c0.w, s.w);
+            }
+            if (flags & MGGCN_SPMM_LEAKY_RELU) {
+                s.x = lrelu(s.x, slope); s.y = lrelu(s.y, slope); s.z = lrelu(s.z, slope); s.w = lrelu(s.w, slope);
+            }
+            *cp = s;
+        };
+#define MGGCN_EMIT(R) emit(R, p0[R], p1[R], p2[R], p3[R]);
+        MGGCN_EMIT(0) MGGCN_EMIT(1) MGGCN_EMIT(2) MGGCN_EMIT(3) MGGCN_EMIT(4) MGGCN_EMIT(5) MGGCN_EMIT(6) MGGCN_EMIT(7)
+        MGGCN_EMIT(8) MGGCN_EMIT(9) MGGCN_EMIT(10) MGGCN_EMIT(11) MGGCN_EMIT(12) MGGCN_EMIT(13) MGGCN_EMIT(14) MGGCN_EMIT(15)
+#undef MGGCN_EMIT
+    }
+}
+
 __global__ __launch_bounds__(256) void sweep_combine_kernel(
     const SweepSplitRow *__restrict__ rows, uint32_t n_split, const float *__restrict__ partial,
     float *__restrict__ C, size_t ldc, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
@@ -284,21 +393,22 @@ struct SweepPlan {
 };
 
 SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
-                            const uint32_t *indices, const float *values, uint32_t max_d) {
+                            const uint32_t *indices, const float *values, uint32_t max_d, bool force) {
     if (!n_rows || !indices || !values) return nullptr;
     if (n_cols > kColMask) return nullptr;                          // column does not fit the packed entry
     static_assert(kRW == 16, "4 row bits in the packed entry");
     const uint64_t nnz = (uint64_t)indptr[n_rows] - indptr[0];
-    if (nnz < env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20)) return nullptr;   // small graphs: row-split is fine
-    const uint32_t panel_rows = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 4096u));
+    if (!force && nnz < env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20)) return nullptr;   // small graphs: row-split is fine
+    const uint32_t panel_rows = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 8192u));
 
     // resident waves per launch ("round").  Registers would admit 6 blocks of 4 waves per CU
     // (56 VGPRs; ~106 SGPRs -> floor(800 / (ceil(sgpr/16)*16 + 16)) = 6, MI355X_MICROARCH.md
     // residency rule), but FEWER waves keep the sweep tighter: the spread of the waves over the
     // column space is what decides the L2 hit rate.  Measured on the Reddit shape, d = 128
     // (profiles/experiments/sweep_vs_rowsplit.py): 2 blocks/CU 3.96 ms, 3 -> 3.34 ms, 4 -> 4.0,
-    // 5 -> 4.0, 6 -> 4.4 (row-split kernel: 5.96 ms).
-    const uint32_t blocks_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 3u), 8u));
+    // 5 -> 4.0, 6 -> 4.4 (row-split kernel: 5.96 ms).  With the float4 pair kernel and 32 MiB
+    // column slices (spmm.hip) the optimum moved to 4 blocks/CU, 8192-row panels: 2.83 ms.
+    const uint32_t blocks_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u), 8u));
     const uint32_t round_tasks = kNumCU * blocks_per_cu * kWavesPerBlock;
 
     // 1. virtual rows: slices of heavy rows get partial-sum slots
@@ -348,65 +458,87 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
         load[t] += vrows[vi].end - vrows[vi].beg;
         if (bins[t].size() < (size_t)kRW) heap.push({load[t], t});
     }
-    // 3. entry stream per task, sorted by (column panel, local row), original order inside a run
+    // 3. entry stream per task, sorted by (column panel, local row), original order inside a run.
+    //    Every (panel,row) run is padded to an EVEN number of entries (a zero-valued copy of its
+    //    last entry) and the two entries of each consecutive pair are ordered by column: the
+    //    float4 kernel gathers one pair per instruction, one entry per half-wave.
+    const uint32_t n_panels = (n_cols + panel_rows - 1) / panel_rows;
+    unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    if (const char *s = std::getenv("MGGCN_HOST_THREADS")) hw = std::max(1u, (unsigned)std::strtoul(s, nullptr, 10));
+    const unsigned NT = nnz > (1u << 22) ? hw : 1u;
+    auto run_parallel = [&](auto &&fn) {
+        if (NT <= 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < NT; i++) th.emplace_back(fn, i);
+        for (auto &x : th) x.join();
+    };
+    const size_t n_buckets = (size_t)n_panels * kRW;
+    auto count_buckets = [&](uint32_t t, std::vector<uint32_t> &cnt) {
+        std::fill(cnt.begin(), cnt.end(), 0u);
+        const auto &bin = bins[t];
+        for (size_t r = 0; r < bin.size(); r++) {
+            const VRow &v = vrows[bin[r]];
+            for (uint32_t e = v.beg; e < v.end; e++) {
+                MGGCN_REQUIRE(indices[e] < n_cols, "column index out of range");
+                cnt[(size_t)(indices[e] / panel_rows) * kRW + r]++;
+            }
+        }
+    };
+    std::vector<uint64_t> plen(T, 0);
+    run_parallel([&](unsigned tid) {
+        std::vector<uint32_t> cnt(n_buckets);
+        for (uint32_t t = tid; t < T; t += NT) {
+            count_buckets(t, cnt);
+            uint64_t len = 0;
+            for (uint32_t c : cnt) len += (c + 1u) & ~1u;
+            plen[t] = len;
+        }
+    });
     std::vector<SweepTask> tasks(T);
     std::vector<uint32_t> task_rows((size_t)T * kRW, 0u);
     uint64_t off = 0;
     for (uint32_t t = 0; t < T; t++) {
         tasks[t].beg = (uint32_t)off;
-        off += (load[t] + 7) / 8 * 8;                 // whole 8-entry (64-byte) batches
+        off += (plen[t] + 7) / 8 * 8;                 // whole 8-entry (64-byte) batches
         tasks[t].end = (uint32_t)off;
         tasks[t].n_rows = (uint32_t)bins[t].size();
         tasks[t].pad = 0;
         for (size_t r = 0; r < bins[t].size(); r++) task_rows[(size_t)t * kRW + r] = vrows[bins[t][r]].dst;
     }
     MGGCN_REQUIRE(off < (1ull << 32), "sweep plan: entry stream exceeds 32-bit offsets");
-    const uint64_t n_entries = off;
-    std::vector<uint2> entries(n_entries);
-    const uint32_t n_panels = (n_cols + panel_rows - 1) / panel_rows;
-    unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-    if (const char *s = std::getenv("MGGCN_HOST_THREADS")) hw = std::max(1u, (unsigned)std::strtoul(s, nullptr, 10));
-    const unsigned NT = nnz > (1u << 22) ? hw : 1u;
-    auto worker = [&](unsigned tid) {
-        std::vector<uint32_t> cnt((size_t)n_panels * kRW + 1), cnt_start;
+    std::vector<uint2> entries(off);
+    run_parallel([&](unsigned tid) {
+        std::vector<uint32_t> cnt(n_buckets), start(n_buckets + 1), cur(n_buckets);
         for (uint32_t t = tid; t < T; t += NT) {
-            std::fill(cnt.begin(), cnt.end(), 0u);
-            const auto &bin = bins[t];
-            for (size_t r = 0; r < bin.size(); r++) {
-                const VRow &v = vrows[bin[r]];
-                for (uint32_t e = v.beg; e < v.end; e++) cnt[(size_t)(indices[e] / panel_rows) * kRW + r + 1]++;
-            }
-            for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+            count_buckets(t, cnt);
+            start[0] = 0;
+            for (size_t k = 0; k < n_buckets; k++) start[k + 1] = start[k] + ((cnt[k] + 1u) & ~1u);
+            std::copy(start.begin(), start.begin() + n_buckets, cur.begin());
             uint2 *out = entries.data() + tasks[t].beg;
-            std::vector<uint32_t> &run_start = cnt_start;
-            run_start.assign(cnt.begin(), cnt.end());            // bucket start offsets (before filling)
+            const auto &bin = bins[t];
             for (size_t r = 0; r < bin.size(); r++) {
                 const VRow &v = vrows[bin[r]];
                 for (uint32_t e = v.beg; e < v.end; e++) {
                     const uint32_t c = indices[e];
-                    MGGCN_REQUIRE(c < n_cols, "column index out of range");
-                    const uint32_t at = cnt[(size_t)(c / panel_rows) * kRW + r]++;
+                    const uint32_t at = cur[(size_t)(c / panel_rows) * kRW + r]++;
                     uint32_t vb;
                     std::memcpy(&vb, &values[e], 4);
                     out[at] = make_uint2((((uint32_t)r & (kRW - 1)) << kColBits) | c, vb);
                 }
             }
-            // mark the first entry of every non-empty (panel,row) bucket
-            const uint32_t real = (uint32_t)load[t], padded = tasks[t].end - tasks[t].beg;
-            for (size_t k = 0; k + 1 < run_start.size(); k++)
-                if (run_start[k + 1] > run_start[k]) out[run_start[k]].x |= kRunFlag;
-            // padding: zero-valued copies of the last entry without the run flag (no extra fold,
-            // same column -> an L2 hit); an empty task has no batches at all
+            for (size_t k = 0; k < n_buckets; k++) {
+                if (!cnt[k]) continue;
+                const uint32_t s0 = start[k], s1 = start[k + 1];
+                if (cnt[k] & 1u) out[s1 - 1] = make_uint2(out[s1 - 2].x, 0u);       // even out the run
+                for (uint32_t q = s0; q < s1; q += 2)                                // pair: lower column first
+                    if ((out[q].x & kColMask) > (out[q + 1].x & kColMask)) std::swap(out[q], out[q + 1]);
+                out[s0].x |= kRunFlag;                                               // first entry of the run
+            }
+            // tail padding up to the 8-entry batch: zero-valued copies of the last entry, no run flag
+            const uint32_t real = (uint32_t)plen[t], padded = tasks[t].end - tasks[t].beg;
             for (uint32_t k = real; k < padded; k++) out[k] = make_uint2(out[real - 1].x & ~kRunFlag, 0u);
         }
-    };
-    if (NT <= 1) {
-        worker(0);
-    } else {
-        std::vector<std::thread> th;
-        for (unsigned i = 0; i < NT; i++) th.emplace_back(worker, i);
-        for (auto &x : th) x.join();
-    }
+    });
 
     auto *p = new SweepPlan;
     p->n_rows = n_rows; p->n_cols = n_cols; p->max_d = max_d;
@@ -455,18 +587,25 @@ bool sweep_supports(const SweepPlan *p, uint32_t d, size_t ldb, size_t ldc, cons
 
 void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb, float *C, size_t ldc,
                   uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
-    // float2 lanes need 8-byte aligned rows; otherwise one column per lane
+    // float4 pair form: 16-byte aligned rows of >= 96 columns (narrower rows would idle most of
+    // a half-wave); float2 lanes need 8-byte aligned rows; otherwise one column per lane
+    const bool vec4 = d >= 96 && d % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C) &&
+                      env_u32("MGGCN_SPMM_SWEEP_VEC4", 1u) != 0;
     const bool vec2 = d > 64 && d % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 &&
                       (reinterpret_cast<uintptr_t>(B) & 7u) == 0 && (reinterpret_cast<uintptr_t>(C) & 7u) == 0;
     const uint32_t b_bytes = (uint32_t)((uint64_t)p->n_cols * ldb * sizeof(float));
     const uint32_t row_bytes = (uint32_t)(ldb * sizeof(float));
     // narrow rows (one column per lane, <= 256 B per gather) are instruction-bound rather than
     // L2-window-bound: twice the resident waves per round measured faster (d = 41: 2.4 -> 2.0 ms)
-    const uint32_t per_launch = p->round_tasks * (vec2 ? 1u : 2u);
+    const uint32_t per_launch = (vec2 || vec4) ? p->round_tasks : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
     for (uint32_t t0 = 0; t0 < p->n_tasks; t0 += per_launch) {
         const uint32_t n_launch = std::min(per_launch, p->n_tasks - t0);
         const dim3 grid((n_launch + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
-        if (vec2)
+        if (vec4)
+            hipLaunchKernelGGL(spmm_sweep_pair_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
+                               p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
+                               alpha, beta, flags, slope);
+        else if (vec2)
             hipLaunchKernelGGL((spmm_sweep_kernel<2>), grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
                                alpha, beta, flags, slope);

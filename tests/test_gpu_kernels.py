@@ -266,6 +266,7 @@ def force_sweep(monkeypatch):
     and a tiny panel so that the (panel, row) ordering of the entry streams is exercised."""
     monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_NNZ", "1")
     monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS", "64")
+    monkeypatch.setenv("MGGCN_SPMM_SLICE_ROWS", "400")        # several column slices (beta chaining)
     monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
 
 
