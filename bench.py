@@ -200,7 +200,14 @@ def cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d):
     roughly 10-30 s: one d-wide forward SpMM on the full graph, then -- if the projected
     time allows -- one full training epoch; otherwise an epoch on a row-scaled graph."""
     orc = ge.load_oracle()
-    cores = orc.num_threads()
+    # the box gives one GPU's share of the host (16 cores); OpenMP would otherwise start one
+    # thread per visible hardware thread and oversubscribe the cgroup
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("MGGCN_CPU_BASELINE_THREADS", "16"))))
+    orc.lib().orc_set_num_threads(cores)
     A = orc.Csr(indptr, indices, data.copy(), n)
     orc.normalize(A, True)
     A_T = orc.transpose(A)

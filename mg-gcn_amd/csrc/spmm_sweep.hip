@@ -184,28 +184,38 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_kernel(
         Vec<VEC> acc; acc.zero();
 
         if (task.beg < task.end) {
-            EntryBatch cur = load_batch(entries, task.beg);
-            for (uint32_t e = task.beg; e < task.end; e += 8) {
-                const uint32_t e_next = e + 8 < task.end ? e + 8 : e;     // last batch re-reads itself
-                const EntryBatch nxt = load_batch(entries, e_next);
-                Vec<VEC> b[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    b[u] = BufLoad<VEC>::load(rsrc, lane_off, (cur.pk(u) & kColMask) * row_bytes);
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t pk = cur.pk(u);
-                    if (pk & kRunFlag) {                                   // first entry of a (panel,row) run
-                        const float2 a2 = vec_to2<VEC>(acc);
-                        p0[cur_row] += a2.x;
-                        if (VEC == 2) p1[cur_row] += a2.y;
-                        acc.zero();
-                        cur_row = (pk >> kColBits) & (kRW - 1);
-                    }
-                    acc.fma(cur.val(u), b[u]);
-                }
-                cur = nxt;
+            // NOTE: keep this loop body inline.  Wrapping it in a lambda that captures p0/p1 by
+            // reference sends the accumulators to scratch memory (measured: 2.0 -> 14 ms at d = 41).
+            // Two SGPR batch sets used alternately (a macro, not a lambda): this loop is bound by
+            // scalar issue, and copying the 16 batch registers every 8 entries costs 2 SALU per entry.
+#define MGGCN_SWEEP_BODY(cur)                                                                     \
+            {                                                                                     \
+                Vec<VEC> b[8];                                                                    \
+                _Pragma("unroll") for (int u = 0; u < 8; u++)                                     \
+                    b[u] = BufLoad<VEC>::load(rsrc, lane_off, (cur.pk(u) & kColMask) * row_bytes); \
+                _Pragma("unroll") for (int u = 0; u < 8; u++) {                                   \
+                    const uint32_t pk = cur.pk(u);                                                \
+                    if (pk & kRunFlag) { /* first entry of a (panel,row) run */                   \
+                        const float2 a2 = vec_to2<VEC>(acc);                                      \
+                        p0[cur_row] += a2.x;                                                      \
+                        if (VEC == 2) p1[cur_row] += a2.y;                                        \
+                        acc.zero();                                                               \
+                        cur_row = (pk >> kColBits) & (kRW - 1);                                   \
+                    }                                                                             \
+                    acc.fma(cur.val(u), b[u]);                                                    \
+                }                                                                                 \
             }
+            const uint32_t last = task.end - 8;
+            EntryBatch A = load_batch(entries, task.beg);
+            for (uint32_t e = task.beg;; e += 16) {
+                const EntryBatch Bn = load_batch(entries, min(e + 8, last));
+                MGGCN_SWEEP_BODY(A)
+                if (e + 8 >= task.end) break;
+                A = load_batch(entries, min(e + 16, last));
+                MGGCN_SWEEP_BODY(Bn)
+                if (e + 16 >= task.end) break;
+            }
+#undef MGGCN_SWEEP_BODY
         }
         {
             const float2 a2 = vec_to2<VEC>(acc);
@@ -344,6 +354,98 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair_kernel(
             *cp = s;
         };
 #define MGGCN_EMIT(R) emit(R, p0[R], p1[R], p2[R], p3[R]);
+        MGGCN_EMIT(0) MGGCN_EMIT(1) MGGCN_EMIT(2) MGGCN_EMIT(3) MGGCN_EMIT(4) MGGCN_EMIT(5) MGGCN_EMIT(6) MGGCN_EMIT(7)
+        MGGCN_EMIT(8) MGGCN_EMIT(9) MGGCN_EMIT(10) MGGCN_EMIT(11) MGGCN_EMIT(12) MGGCN_EMIT(13) MGGCN_EMIT(14) MGGCN_EMIT(15)
+#undef MGGCN_EMIT
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// float2 pair form for narrow or unaligned rows (d <= 64, any 4-byte alignment; the
+// reference's logits layer has d = 41, 164-byte rows).  Cost model fitted to the measurements
+// of the three kernels above: one row-gather instruction costs ~7 cycles per CU plus
+// bytes/64 -- at 164 B per row the fixed part dominates, so fetching TWO rows per instruction
+// (one per half-wave, 32 lanes x 2 floats) is worth almost 2x.  Same pairing, same index-mode
+// fold, element-wise guarded stores.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair2_kernel(
+    const SweepTask *__restrict__ tasks, uint32_t task0, uint32_t n_launch,
+    const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
+    const float *__restrict__ B, uint32_t b_bytes, uint32_t row_bytes, float *__restrict__ C, size_t ldc,
+    float *__restrict__ partial, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wib = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
+    const uint32_t local = blockIdx.x * kWavesPerBlock + wib;
+    if (local >= n_launch) return;
+    const uint32_t t = task0 + local;
+    const SweepTask task = tasks[t];
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, b_bytes, 0x00020000);
+    const uint32_t sub = lane & 31;
+    const uint32_t hmask = (lane & 32) ? 0xFFFFFFFFu : 0u;
+
+    for (uint32_t col0 = 0; col0 < d; col0 += 64) {
+        const uint32_t col = col0 + sub * 2;
+        const bool act0 = col < d, act1 = col + 1 < d;      // the second float of the last lane may be past the row:
+        const uint32_t lane_off = (act0 ? col : 0) * 4u;    // it is fetched (inside B or zero-filled by the
+        f32x16 p0, p1;                                      // descriptor's bounds check) and never stored
+#pragma unroll
+        for (int r = 0; r < 16; r++) { p0[r] = 0.f; p1[r] = 0.f; }
+        uint32_t cur_row = 0;
+        float a0 = 0.f, a1 = 0.f;
+
+        if (task.beg < task.end) {
+            EntryBatch cur = load_batch(entries, task.beg);
+            for (uint32_t e = task.beg; e < task.end; e += 8) {
+                const uint32_t e_next = e + 8 < task.end ? e + 8 : e;
+                const EntryBatch nxt = load_batch(entries, e_next);
+                f32x2_t b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t off_a = (cur.pk(2 * u) & kColMask) * row_bytes;
+                    const uint32_t off_b = (cur.pk(2 * u + 1) & kColMask) * row_bytes;     // >= off_a
+                    b[u] = mggcn_buffer_load_v2f32(rsrc, (int)(lane_off + ((off_b - off_a) & hmask)), (int)off_a, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t pk = cur.pk(2 * u);
+                    if (pk & kRunFlag) {
+                        p0[cur_row] += a0;
+                        p1[cur_row] += a1;
+                        a0 = 0.f; a1 = 0.f;
+                        cur_row = (pk >> kColBits) & (kRW - 1);
+                    }
+                    const uint32_t va = __builtin_bit_cast(uint32_t, cur.val(2 * u));
+                    const uint32_t vb = __builtin_bit_cast(uint32_t, cur.val(2 * u + 1));
+                    const float v = __builtin_bit_cast(float, (va & ~hmask) | (vb & hmask));
+                    a0 = fmaf(v, b[u][0], a0);
+                    a1 = fmaf(v, b[u][1], a1);
+                }
+                cur = nxt;
+            }
+        }
+        p0[cur_row] += a0;
+        p1[cur_row] += a1;
+
+        auto emit = [&](uint32_t r, float x0, float x1) {
+            x0 += __shfl_xor(x0, 32);
+            x1 += __shfl_xor(x1, 32);
+            if (r >= task.n_rows || !act0 || hmask) return;
+            const uint32_t dst = task_rows[(size_t)t * kRW + r];
+            if (dst & kSlotFlag) {
+                float *pp = partial + (size_t)(dst & ~kSlotFlag) * d + col;
+                pp[0] = x0;
+                if (act1) pp[1] = x1;
+                return;
+            }
+            float *cp = C + (size_t)dst * ldc + col;
+            x0 *= alpha; x1 *= alpha;
+            if (beta != 0.f) { x0 = fmaf(beta, cp[0], x0); if (act1) x1 = fmaf(beta, cp[1], x1); }
+            if (flags & MGGCN_SPMM_LEAKY_RELU) { x0 = lrelu(x0, slope); x1 = lrelu(x1, slope); }
+            cp[0] = x0;
+            if (act1) cp[1] = x1;
+        };
+#define MGGCN_EMIT(R) emit(R, p0[R], p1[R]);
         MGGCN_EMIT(0) MGGCN_EMIT(1) MGGCN_EMIT(2) MGGCN_EMIT(3) MGGCN_EMIT(4) MGGCN_EMIT(5) MGGCN_EMIT(6) MGGCN_EMIT(7)
         MGGCN_EMIT(8) MGGCN_EMIT(9) MGGCN_EMIT(10) MGGCN_EMIT(11) MGGCN_EMIT(12) MGGCN_EMIT(13) MGGCN_EMIT(14) MGGCN_EMIT(15)
 #undef MGGCN_EMIT
@@ -597,12 +699,20 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
     const uint32_t row_bytes = (uint32_t)(ldb * sizeof(float));
     // narrow rows (one column per lane, <= 256 B per gather) are instruction-bound rather than
     // L2-window-bound: twice the resident waves per round measured faster (d = 41: 2.4 -> 2.0 ms)
+    // narrow rows: the float2 pair kernel (any alignment)
+    // (measured no faster than the one-column-per-lane kernel at d = 41, 2.2 vs 2.1 ms: that shape is
+    //  bound by scalar issue, ~7 SALU per non-zero, not by gather instructions -> opt-in only)
+    const bool pair2 = !vec4 && d <= 64 && env_u32("MGGCN_SPMM_SWEEP_PAIR2", 0u) != 0;
     const uint32_t per_launch = (vec2 || vec4) ? p->round_tasks : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
     for (uint32_t t0 = 0; t0 < p->n_tasks; t0 += per_launch) {
         const uint32_t n_launch = std::min(per_launch, p->n_tasks - t0);
         const dim3 grid((n_launch + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
         if (vec4)
             hipLaunchKernelGGL(spmm_sweep_pair_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
+                               p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
+                               alpha, beta, flags, slope);
+        else if (pair2)
+            hipLaunchKernelGGL(spmm_sweep_pair2_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
                                alpha, beta, flags, slope);
         else if (vec2)

@@ -13,7 +13,7 @@ import torch
 (ip, ix, dv), _, _ = pkg.datasets.synth_reddit_like(1.0, seed=1)
 n = ip.shape[0] - 1
 ctx = pkg.context(0)
-d = 128
+d = int(os.environ.get("EXP_WD", "128"))
 B = pkg.dn_matrix.from_numpy(np.random.default_rng(0).standard_normal((n, d), dtype=np.float32))
 C = pkg.dn_matrix(n, d)
 rng = np.random.default_rng(1)
@@ -33,5 +33,5 @@ for W in [int(x) for x in os.environ.get("EXP_WINDOWS", "2048,4096,8192,16384,32
     ctx.sync()
     ctx.register_timer("t", "a", "b")
     ms = ctx.measure("t") / 5
-    print(f"{ALGO} window {W:7d} rows = {W*512/2**20:7.2f} MiB : {ms:7.3f} ms/SpMM, gather {ix.shape[0]*512/ms/1e9:8.1f} TB/s", flush=True)
+    print(f"{ALGO} window {W:7d} rows = {W*512/2**20:7.2f} MiB : {ms:7.3f} ms/SpMM, gather {ix.shape[0]*4*d/ms/1e9:8.1f} TB/s", flush=True)
     del A, buf
