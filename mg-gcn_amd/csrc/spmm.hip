@@ -326,26 +326,51 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_co
         // boundary re-synchronises the chip.  Costs one extra read+write of C per extra slice.
         const uint64_t slice_rows = std::max<uint64_t>(
             64, env_u32("MGGCN_SPMM_SLICE_ROWS", env_u32("MGGCN_SPMM_SLICE_MIB", 32u) * 2048u));   // tests set ROWS
-        const uint32_t S = (uint32_t)std::max<uint64_t>(1, ((uint64_t)n_cols + slice_rows - 1) / slice_rows);
-        if (S <= 1) {
-            if (SweepPlan *sp = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d))
+        uint32_t S = (uint32_t)std::max<uint64_t>(1, ((uint64_t)n_cols + slice_rows - 1) / slice_rows);
+        const uint64_t total_nnz = n_rows ? (uint64_t)host_indptr[n_rows] - host_indptr[0] : 0;
+        // The sweep pays only for DENSE rows: its unit of work is a (panel,row) run, and a graph
+        // whose rows have fewer non-zeros than there are panels degenerates into one fold per
+        // entry.  Measured at the ogbn-products shape (n = 2.45 M, mean degree 51, B = 1.25 GB):
+        // row-split 8.2 ms, sweep 15-38 ms (profiles/experiments/products_like.py).  Gate: mean
+        // run length >= 2, and never more slices than leave ~64 non-zeros per (row, slice).
+        const double avg_deg = n_rows ? (double)total_nnz / n_rows : 0.0;
+        const double panel_rows = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 8192u));
+        const double mean_run = n_cols ? avg_deg * std::min<double>(panel_rows, n_cols) / n_cols : 0.0;
+        if (!std::getenv("MGGCN_SPMM_SLICE_ROWS")) S = std::max<uint32_t>(1u, std::min<uint32_t>(S, (uint32_t)(avg_deg / 64.0)));
+        const bool worth_it = total_nnz >= env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20) &&   // small graphs: row-split is fine
+                              mean_run * 10.0 >= env_u32("MGGCN_SPMM_SWEEP_MIN_RUN_X10", 20u);
+        if (!worth_it) {
+            // nothing
+        } else if (S <= 1) {
+            if (SweepPlan *sp = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d, true))
                 plan->sweeps.push_back(sp);
         } else {
+            // bucket the non-zeros by column slice: two passes over A whatever the slice count
             const uint32_t width = (n_cols + S - 1) / S;
-            std::vector<uint32_t> ip((size_t)n_rows + 1), ix;
-            std::vector<float> vv;
-            bool ok = true;
-            for (uint32_t sidx = 0; sidx < S && ok; sidx++) {
-                const uint32_t lo = sidx * width, hi = std::min<uint64_t>(n_cols, (uint64_t)lo + width);
-                ix.clear(); vv.clear();
-                ip[0] = 0;
-                for (uint32_t r = 0; r < n_rows; r++) {
-                    for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++)
-                        if (host_indices[e] >= lo && host_indices[e] < hi) { ix.push_back(host_indices[e]); vv.push_back(host_values[e]); }
-                    ip[r + 1] = (uint32_t)ix.size();
+            std::vector<std::vector<uint32_t>> ips(S, std::vector<uint32_t>((size_t)n_rows + 1, 0u));
+            for (uint32_t r = 0; r < n_rows; r++)
+                for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) ips[host_indices[e] / width][r + 1]++;
+            std::vector<std::vector<uint32_t>> ixs(S);
+            std::vector<std::vector<float>> vvs(S);
+            for (uint32_t k = 0; k < S; k++) {
+                for (uint32_t r = 0; r < n_rows; r++) ips[k][r + 1] += ips[k][r];
+                ixs[k].resize(ips[k][n_rows]);
+                vvs[k].resize(ips[k][n_rows]);
+            }
+            std::vector<uint32_t> pos(S, 0u);          // rows are visited in order: one cursor per slice
+            for (uint32_t r = 0; r < n_rows; r++)
+                for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) {
+                    const uint32_t k = host_indices[e] / width;
+                    ixs[k][pos[k]] = host_indices[e];
+                    vvs[k][pos[k]] = host_values[e];
+                    pos[k]++;
                 }
-                SweepPlan *sp = sweep_plan_build(n_rows, n_cols, ip.data(), ix.data(), vv.data(), max_d, /*force=*/sidx > 0);
+            bool ok = true;
+            for (uint32_t k = 0; k < S && ok; k++) {
+                SweepPlan *sp = sweep_plan_build(n_rows, n_cols, ips[k].data(), ixs[k].data(), vvs[k].data(), max_d, true);
                 if (sp) plan->sweeps.push_back(sp); else ok = false;
+                std::vector<uint32_t>().swap(ixs[k]);        // release as we go
+                std::vector<float>().swap(vvs[k]);
             }
             if (!ok) {                                   // all or nothing: the slices must cover A
                 for (auto *sp : plan->sweeps) sweep_plan_destroy(sp);

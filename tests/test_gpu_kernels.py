@@ -267,6 +267,7 @@ def force_sweep(monkeypatch):
     monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_NNZ", "1")
     monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS", "64")
     monkeypatch.setenv("MGGCN_SPMM_SLICE_ROWS", "400")        # several column slices (beta chaining)
+    monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_RUN_X10", "0")   # sparse test rows would be sent to row-split
     monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
 
 
@@ -319,7 +320,7 @@ def test_sweep_equals_rowsplit_on_a_big_graph(pkg, ctx, monkeypatch):
     z = np.zeros((n, d), np.float32)
     monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
     s, bs = _run_spmm(pkg, ctx, A, B, z, 1.0, 0.0)
-    assert bs.num_sweep_tasks() > 0
+    assert bs.num_sweep_tasks() > 0                       # mean degree 75 over 40 k columns: dense enough
     monkeypatch.setenv("MGGCN_SPMM_ALGO", "rowsplit")
     r, br = _run_spmm(pkg, ctx, A, B, z, 1.0, 0.0)
     assert br.num_sweep_tasks() == 0
