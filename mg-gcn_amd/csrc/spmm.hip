@@ -367,6 +367,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_co
                 }
             bool ok = true;
             for (uint32_t k = 0; k < S && ok; k++) {
+                if (ixs[k].empty()) continue;            // e.g. a rank's own column range in its "remote" matrix
                 SweepPlan *sp = sweep_plan_build(n_rows, n_cols, ips[k].data(), ixs[k].data(), vvs[k].data(), max_d, true);
                 if (sp) plan->sweeps.push_back(sp); else ok = false;
                 std::vector<uint32_t>().swap(ixs[k]);        // release as we go

@@ -514,7 +514,10 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     const uint32_t round_tasks = kNumCU * blocks_per_cu * kWavesPerBlock;
 
     // 1. virtual rows: slices of heavy rows get partial-sum slots
-    const uint32_t t_est = (n_rows + kRW - 1) / kRW;
+    // rows per task: 16 when there are enough rows to fill a round, fewer for small row blocks
+    // (a rank's share at P = 8 has 29 k rows: 16 rows per wave would leave 7 waves per CU)
+    const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)kRW, (n_rows + round_tasks - 1) / round_tasks));
+    const uint32_t t_est = (n_rows + cap_rows - 1) / cap_rows;
     const uint32_t target = (uint32_t)std::max<uint64_t>(1, nnz / t_est);
     const uint32_t split = std::max<uint32_t>(256u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_SPLIT", target / 2), 1u << 20));
     std::vector<VRow> vrows;
@@ -538,7 +541,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
         }
     }
     // 2. tasks: equal-work bins of <= RW virtual rows (longest first into the lightest bin)
-    uint32_t T = (uint32_t)((vrows.size() + kRW - 1) / kRW);
+    uint32_t T = (uint32_t)((vrows.size() + cap_rows - 1) / cap_rows);
     if (T > round_tasks) T = (T + round_tasks - 1) / round_tasks * round_tasks;
     T = std::max<uint32_t>(T, 1u);
     std::vector<uint32_t> order(vrows.size());
@@ -558,7 +561,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
         const uint32_t t = top.second;
         bins[t].push_back(vi);
         load[t] += vrows[vi].end - vrows[vi].beg;
-        if (bins[t].size() < (size_t)kRW) heap.push({load[t], t});
+        if (bins[t].size() < (size_t)cap_rows) heap.push({load[t], t});
     }
     // 3. entry stream per task, sorted by (column panel, local row), original order inside a run.
     //    Every (panel,row) run is padded to an EVEN number of entries (a zero-valued copy of its
