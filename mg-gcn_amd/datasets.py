@@ -197,3 +197,50 @@ def synth_reddit_like(scale: float = 1.0, seed: int = 1):
     Y = rng.integers(0, REDDIT_SHAPE["classes"], size=(n, 1)).astype(np.int32)
     Y[0, 0] = REDDIT_SHAPE["classes"] - 1          # num_labels = 1 + max(Y) (main.cpp:89)
     return (indptr, indices, data), X, Y
+
+
+# ----------------------------------------------------------------------------
+# Data preparation without DGL: what the reference's
+# test/data/prep.py does to a graph before writing it (serialize_dgl_graph :100-126 and
+# serialize_dataset :78-99), on plain numpy / scipy inputs.
+# ----------------------------------------------------------------------------
+def prepare_dataset(dirname: str, adj, features, labels, sets=None, P: int = 8, seed: int = 0) -> str:
+    """adj: scipy sparse (n x n) or (indptr, indices, data) CSR triple; features [n x F];
+    labels [n]; sets [n] in {0 train, 1 val, 2 test}.
+      * pads the vertex count and the feature width to multiples of P with zero vertices /
+        zero columns (prep.py:101-103, :122-124; padding vertices get label 0, set 0),
+      * adds a self-loop to every vertex, padding included (prep.py:113),
+      * seed != 0: applies one random symmetric permutation to graph, features, labels, sets
+        and writes under <dirname>/permuted/... like prep.py:80-94,
+      * writes graph.bin / features.bin / labels.bin / sets.bin.  Returns the directory."""
+    import scipy.sparse as sp
+    if isinstance(adj, tuple):
+        ip, ix, dv = adj
+        n0 = len(ip) - 1
+        adj = sp.csr_matrix((np.asarray(dv, dtype=np.float32), np.asarray(ix), np.asarray(ip)), shape=(n0, n0))
+    adj = sp.csr_matrix(adj, dtype=np.float32)
+    n0 = adj.shape[0]
+    features = np.asarray(features, dtype=np.float32).reshape(n0, -1)
+    labels = np.asarray(labels).reshape(n0).astype(np.int64)
+    sets = np.zeros(n0, dtype=np.int64) if sets is None else np.asarray(sets).reshape(n0).astype(np.int64)
+    n = (n0 + P - 1) // P * P
+    F0 = features.shape[1]
+    F = (F0 + P - 1) // P * P
+    adj = sp.csr_matrix((adj.data, adj.indices, np.concatenate([adj.indptr, np.full(n - n0, adj.indptr[-1])])), shape=(n, n))
+    adj = sp.csr_matrix(adj + sp.eye(n, dtype=np.float32, format="csr") - sp.diags(adj.diagonal(), format="csr"))
+    adj.data[:] = np.where(adj.data != 0, adj.data, 1.0)
+    feats = np.zeros((n, F), dtype=np.float32)
+    feats[:n0, :F0] = features
+    labs = np.zeros(n, dtype=np.int64); labs[:n0] = labels
+    st = np.zeros(n, dtype=np.int64); st[:n0] = sets
+    out = dirname
+    if seed != 0:
+        head, tail = os.path.split(os.path.normpath(dirname))
+        out = os.path.join(head, "permuted", tail)
+        perm = np.random.default_rng(seed).permutation(n)
+        adj = adj[perm][:, perm]
+        feats, labs, st = feats[perm], labs[perm], st[perm]
+    adj = sp.csr_matrix(adj)
+    adj.sort_indices()
+    write_dataset(out, adj.indptr, adj.indices, adj.data, feats, labs, st)
+    return out

@@ -360,3 +360,23 @@ class gcn:
 
     def layers(self) -> List[gcn_layer]:
         return self.layers_
+
+    def evaluate(self, ctx: context, H: dn_matrix, Y: dn_matrix, S: Optional[dn_matrix] = None):
+        """Forward pass + accuracy per split.  The reference loads
+        sets.bin (0 train / 1 val / 2 test, test/data/prep.py:115-118) and never uses it
+        (src/main.cpp:85); its reported accuracy is over ALL vertices, which is what
+        ``result["all"]`` repeats.  Device work: the model's forward kernels + the argmax
+        kernel; the per-split counting is a host reduction over n integers."""
+        out = self(ctx, H)
+        P = dn_matrix(Y.shape(), dtype=np.int32)
+        ops.max_row_indices(ctx, out, P)
+        ctx.sync()
+        pred, y = P.numpy().reshape(-1), Y.numpy().reshape(-1)
+        hit = pred == y
+        res = {"all": float(hit.mean())}
+        if S is not None:
+            s = S.numpy().reshape(-1)
+            for k, name in ((0, "train"), (1, "val"), (2, "test")):
+                m = s == k
+                res[name] = float(hit[m].mean()) if m.any() else float("nan")
+        return res

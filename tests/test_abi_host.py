@@ -160,3 +160,37 @@ def test_synthetic_generators_hit_their_shapes(pkg):
     (g, X, Y) = ds.synth_reddit_like(scale=0.002, seed=1)
     assert g[0].shape[0] - 1 == X.shape[0] == Y.shape[0] and X.shape[1] == 608 and Y.max() == 40
     assert X.shape[0] % 8 == 0
+
+
+def test_prepare_dataset_pads_loops_and_permutes(pkg, tmp_path):
+    """the reference's data-prep steps (test/data/prep.py:78-126) without DGL"""
+    import scipy.sparse as sp
+    ds = pkg.datasets
+    n0, F0 = 13, 5
+    rng = np.random.default_rng(0)
+    adj = sp.random(n0, n0, density=0.3, format="csr", dtype=np.float32, random_state=1)
+    adj.data[:] = 1.0
+    X = rng.standard_normal((n0, F0)).astype(np.float32)
+    Y = rng.integers(0, 4, size=n0)
+    S = rng.integers(0, 3, size=n0)
+    d = ds.prepare_dataset(str(tmp_path / "g"), adj, X, Y, S, P=8, seed=0)
+    (ip, ix, dv, n, m), X2, Y2, S2 = ds.read_dataset(d)
+    assert n == m == 16 and X2.shape == (16, 8)                         # padded to multiples of 8
+    dense = sp.csr_matrix((dv, ix, ip), shape=(n, n)).toarray()
+    assert (np.diag(dense) == 1).all()                                   # self-loops, padding vertices too
+    off = dense - np.diag(np.diag(dense))
+    want = adj.toarray() - np.diag(np.diag(adj.toarray()))
+    np.testing.assert_array_equal(off[:n0, :n0], want)
+    assert off[n0:].sum() == 0 and off[:, n0:].sum() == 0
+    np.testing.assert_array_equal(X2[:n0, :F0], X); assert X2[n0:].sum() == 0 and X2[:, F0:].sum() == 0
+    np.testing.assert_array_equal(Y2.reshape(-1)[:n0], Y); np.testing.assert_array_equal(S2.reshape(-1)[:n0], S)
+    # permuted variant: same multiset of degrees / labels, written under permuted/
+    d2 = ds.prepare_dataset(str(tmp_path / "g"), adj, X, Y, S, P=8, seed=3)
+    assert os.path.normpath(d2).endswith(os.path.join("permuted", "g"))
+    (ip2, ix2, dv2, _, _), X3, Y3, _ = ds.read_dataset(d2)
+    assert sorted(np.diff(ip2).tolist()) == sorted(np.diff(ip).tolist())
+    assert sorted(Y3.reshape(-1).tolist()) == sorted(Y2.reshape(-1).tolist())
+    dense2 = sp.csr_matrix((dv2, ix2, ip2), shape=(n, n)).toarray()
+    perm = np.random.default_rng(3).permutation(n)
+    np.testing.assert_array_equal(dense2, dense[perm][:, perm])
+    np.testing.assert_array_equal(X3, X2[perm])

@@ -249,3 +249,29 @@ def test_full_reddit_shape_properties(pkg, ctx):
     C2 = pkg.dn_matrix(n, d)
     pkg.matmul(ctx, A_T, B2, C2, buf_f, 1.0, 0.0); ctx.sync()
     assert torch.equal(C2.t, 2 * C.t)
+
+
+def test_evaluate_per_split_accuracy(pkg, oracle, ctx):
+    """sets.bin masks: accuracy per split from the device forward +
+    argmax; "all" equals the reference's whole-graph accuracy (gcn.hpp:816-817)."""
+    n, sizes = 1024, [16, 8, 4]
+    ip, ix, dv = pkg.datasets.synth_uniform_csr(n, 6, seed=5)
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((n, 16)).astype(np.float32)
+    Y = rng.integers(0, 4, size=(n, 1)).astype(np.int32)
+    S = rng.integers(0, 3, size=(n, 1)).astype(np.int32)
+    G = pkg.gcn(pkg.csr_matrix(ip, ix, dv, n), sizes)
+    O = oracle.Gcn(oracle.Csr(ip, ix, dv, n), sizes)
+    dX, dY, dS = (pkg.dn_matrix.from_numpy(a) for a in (X, Y, S))
+    res = G.evaluate(ctx, dX, dY, dS)
+    _, acc = G.train_forward(ctx, dX, dY)
+    assert abs(res["all"] - acc) < 1e-6
+    out = O.forward(X) if hasattr(O, "forward") else None
+    if out is not None:
+        pred = out.argmax(axis=1)
+        for k, name in enumerate(["train", "val", "test"]):
+            m = S.reshape(-1) == k
+            want = float((pred[m] == Y.reshape(-1)[m]).mean())
+            assert abs(res[name] - want) <= 2.0 / m.sum()      # argmax ties under 1e-4 fp noise
+    tot = sum(res[k] * (S.reshape(-1) == i).sum() for i, k in enumerate(["train", "val", "test"]))
+    assert abs(tot / n - res["all"]) < 1e-6
