@@ -106,6 +106,15 @@ typedef struct mggcn_spmm_plan mggcn_spmm_plan;
 mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,
                                         const uint32_t *host_indptr, const uint32_t *host_indices,
                                         const float *host_values, uint32_t max_d);
+/* Same, with the feature width the plan will mostly be used at (the reference sizes its cuSPARSE
+ * workspace per (A, B, C) triple as well, src/cuda_utils.hpp:94-102, and caches it per width,
+ * src/gcn.hpp:28-31).  d_hint in 1..64 builds the sweep form for NARROW rows (four entries per
+ * gather instruction, B re-pitched to 16-byte rows in a plan-owned scratch); 0 or > 64 is the
+ * form mggcn_spmm_plan_create builds.  Any plan serves any width <= max_d; the hint only picks
+ * which one is fast. */
+mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t n_cols,
+                                            const uint32_t *host_indptr, const uint32_t *host_indices,
+                                            const float *host_values, uint32_t max_d, uint32_t d_hint);
 void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan);
 /* introspection (tests, DESIGN.md figures) */
 uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan);

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "mggcn_memcpy_d2d": (None, [vp, vp, c_size_t, vp]),
     "mggcn_memset_zero": (None, [vp, c_size_t, vp]),
     "mggcn_spmm_plan_create": (vp, [c_uint32, c_uint32, vp, vp, vp, c_uint32]),
+    "mggcn_spmm_plan_create_for": (vp, [c_uint32, c_uint32, vp, vp, vp, c_uint32, c_uint32]),
     "mggcn_spmm_plan_destroy": (None, [vp]),
     "mggcn_spmm_plan_num_items": (c_uint32, [vp]),
     "mggcn_spmm_plan_num_split_rows": (c_uint32, [vp]),

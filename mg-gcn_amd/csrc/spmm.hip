@@ -261,13 +261,26 @@ struct mggcn_spmm_plan {
     // column-panel sweep form (large matrices; spmm_sweep.hip): one plan per column SLICE of
     // the matrix, run back to back with beta accumulation (see mggcn_spmm_plan_create)
     std::vector<SweepPlan *> sweeps;
+    // narrow form (d_hint <= 64): scratch for B re-pitched to 16-byte rows, n_cols x bpad_dp floats
+    float *d_bpad = nullptr;
+    uint32_t bpad_dp = 0;
 };
 
 MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,
                                                   const uint32_t *host_indptr,
                                                   const uint32_t *host_indices,
                                                   const float *host_values, uint32_t max_d) {
+    return mggcn_spmm_plan_create_for(n_rows, n_cols, host_indptr, host_indices, host_values, max_d, 0);
+}
+
+MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t n_cols,
+                                                      const uint32_t *host_indptr,
+                                                      const uint32_t *host_indices,
+                                                      const float *host_values, uint32_t max_d,
+                                                      uint32_t d_hint) {
     MGGCN_REQUIRE(host_indptr != nullptr || n_rows == 0, "plan needs the host copy of indptr");
+    const bool narrow = d_hint >= 1 && d_hint <= 64 && n_cols <= (1u << 24);
+    if (!narrow) d_hint = 0;
     MGGCN_REQUIRE(max_d > 0, "max_d must be positive");
     // slice length for heavy rows; rows up to 1.5x the slice stay whole
     const uint32_t split = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_SPLIT", 512u));
@@ -324,8 +337,9 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_co
         // slower).  So B is cut into slices of <= MGGCN_SPMM_SLICE_MIB (at 512-byte rows) and
         // C = beta C + alpha sum_s A[:, slice s] B is evaluated slice after slice: every launch
         // boundary re-synchronises the chip.  Costs one extra read+write of C per extra slice.
+        const uint32_t hint_bytes = narrow ? (d_hint + 3) / 4 * 16 : 512u;
         const uint64_t slice_rows = std::max<uint64_t>(
-            64, env_u32("MGGCN_SPMM_SLICE_ROWS", env_u32("MGGCN_SPMM_SLICE_MIB", 32u) * 2048u));   // tests set ROWS
+            64, env_u32("MGGCN_SPMM_SLICE_ROWS", (uint32_t)(((uint64_t)env_u32("MGGCN_SPMM_SLICE_MIB", 32u) << 20) / hint_bytes)));   // tests set ROWS
         uint32_t S = (uint32_t)std::max<uint64_t>(1, ((uint64_t)n_cols + slice_rows - 1) / slice_rows);
         const uint64_t total_nnz = n_rows ? (uint64_t)host_indptr[n_rows] - host_indptr[0] : 0;
         // The sweep pays only for DENSE rows: its unit of work is a (panel,row) run, and a graph
@@ -334,7 +348,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_co
         // row-split 8.2 ms, sweep 15-38 ms (profiles/experiments/products_like.py).  Gate: mean
         // run length >= 2, and never more slices than leave ~64 non-zeros per (row, slice).
         const double avg_deg = n_rows ? (double)total_nnz / n_rows : 0.0;
-        const double panel_rows = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 8192u));
+        const double panel_rows = sweep_panel_rows(d_hint);
         const double mean_run = n_cols ? avg_deg * std::min<double>(panel_rows, n_cols) / n_cols : 0.0;
         if (!std::getenv("MGGCN_SPMM_SLICE_ROWS")) S = std::max<uint32_t>(1u, std::min<uint32_t>(S, (uint32_t)(avg_deg / 64.0)));
         const bool worth_it = total_nnz >= env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20) &&   // small graphs: row-split is fine
@@ -342,7 +356,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_co
         if (!worth_it) {
             // nothing
         } else if (S <= 1) {
-            if (SweepPlan *sp = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d, true))
+            if (SweepPlan *sp = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d, true, d_hint))
                 plan->sweeps.push_back(sp);
         } else {
             // bucket the non-zeros by column slice: two passes over A whatever the slice count
@@ -368,7 +382,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_co
             bool ok = true;
             for (uint32_t k = 0; k < S && ok; k++) {
                 if (ixs[k].empty()) continue;            // e.g. a rank's own column range in its "remote" matrix
-                SweepPlan *sp = sweep_plan_build(n_rows, n_cols, ips[k].data(), ixs[k].data(), vvs[k].data(), max_d, true);
+                SweepPlan *sp = sweep_plan_build(n_rows, n_cols, ips[k].data(), ixs[k].data(), vvs[k].data(), max_d, true, d_hint);
                 if (sp) plan->sweeps.push_back(sp); else ok = false;
                 std::vector<uint32_t>().swap(ixs[k]);        // release as we go
                 std::vector<float>().swap(vvs[k]);
@@ -377,6 +391,12 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_co
                 for (auto *sp : plan->sweeps) sweep_plan_destroy(sp);
                 plan->sweeps.clear();
             }
+        }
+        if (narrow && !plan->sweeps.empty()) {
+            plan->bpad_dp = (d_hint + 3) / 4 * 4;
+            const size_t bb = (size_t)n_cols * plan->bpad_dp * sizeof(float);
+            MGGCN_CHECK_HIP(hipMalloc(&plan->d_bpad, bb));
+            plan->bytes += bb;
         }
     }
     return plan;
@@ -388,6 +408,7 @@ MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {
     if (plan->d_items) MGGCN_CHECK_HIP(hipFree(plan->d_items));
     if (plan->d_split) MGGCN_CHECK_HIP(hipFree(plan->d_split));
     if (plan->d_partial) MGGCN_CHECK_HIP(hipFree(plan->d_partial));
+    if (plan->d_bpad) MGGCN_CHECK_HIP(hipFree(plan->d_bpad));
     delete plan;
 }
 
@@ -453,6 +474,12 @@ MGGCN_API void mggcn_spmm_csr_f32(mggcn_stream_t stream, const mggcn_spmm_plan *
         MGGCN_REQUIRE(d <= plan->max_d || plan->n_slots == 0, "feature width exceeds the plan's max_d");
         if (!plan->sweeps.empty() && sweep_supports(plan->sweeps[0], d, ldb, ldc, B, C)) {
             const size_t S = plan->sweeps.size();
+            const uint32_t dp = (d + 3) / 4 * 4;
+            if (plan->d_bpad && dp <= plan->bpad_dp && sweep_wants_repack(plan->sweeps[0], d, ldb, B)) {
+                sweep_repack(st, B, ldb, n_cols, d, plan->d_bpad, dp);     // 16-byte pitched copy of B
+                B = plan->d_bpad;
+                ldb = dp;
+            }
             for (size_t k = 0; k < S; k++)       // beta only once, the fused activation only on the full sum
                 sweep_launch(st, plan->sweeps[k], B, ldb, C, ldc, d, alpha, k == 0 ? beta : 1.f,
                              k + 1 == S ? flags : 0u, slope);

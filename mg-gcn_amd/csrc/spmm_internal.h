@@ -10,7 +10,13 @@ struct SweepPlan;   // opaque to spmm.hip
 // Returns nullptr when the matrix is not worth sweeping (tiny).
 // force: build even below the size threshold (later column slices of a sliced matrix)
 SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
-                            const uint32_t *indices, const float *values, uint32_t max_d, bool force = false);
+                            const uint32_t *indices, const float *values, uint32_t max_d, bool force = false,
+                            uint32_t d_hint = 0);
+// d_hint in 1..64 builds the narrow ("quad") form: runs padded to four entries, wider panels
+uint32_t sweep_panel_rows(uint32_t d_hint);
+// narrow form only: true when B has to be re-pitched to 16-byte rows before sweep_launch
+bool sweep_wants_repack(const SweepPlan *p, uint32_t d, size_t ldb, const void *B);
+void sweep_repack(hipStream_t st, const float *B, size_t ldb, uint32_t n_cols, uint32_t d, float *out, uint32_t dp);
 void sweep_plan_destroy(SweepPlan *p);
 size_t sweep_plan_bytes(const SweepPlan *p);
 uint32_t sweep_plan_tasks(const SweepPlan *p);

@@ -361,95 +361,145 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// float2 pair form for narrow or unaligned rows (d <= 64, any 4-byte alignment; the
-// reference's logits layer has d = 41, 164-byte rows).  Cost model fitted to the measurements
-// of the three kernels above: one row-gather instruction costs ~7 cycles per CU plus
-// bytes/64 -- at 164 B per row the fixed part dominates, so fetching TWO rows per instruction
-// (one per half-wave, 32 lanes x 2 floats) is worth almost 2x.  Same pairing, same index-mode
-// fold, element-wise guarded stores.
+// float4 "quad" form for narrow rows (d <= 64; the reference's logits layer has d = 41).
+// Measured cost of one row-gather wave-instruction on this chip, in cycles per CU, everything
+// hitting L1/L2 (profiles/experiments/narrow_spmm.py, l2_window.py): dword 11, dwordx2 18,
+// dwordx4 22-26 -- nearly independent of how many lanes are live or how many bytes come back.
+// The one-column-per-lane kernel spends a whole instruction on one 164-byte row (2.12 ms on the
+// Reddit shape, with or without L2 locality).  Here B is first re-pitched to a multiple of 4
+// floats (sweep_repack_kernel: 16-byte aligned rows, one streaming pass of n_cols x d floats), a
+// row is 16 lanes x float4 and ONE buffer_load_dwordx4 fetches the rows of FOUR entries, one per
+// quarter-wave (the plan pads every run to a multiple of four): 6.5 cycles per entry instead of
+// 11.  All four quarters accumulate the SAME output row (wave-uniform -> index-mode fold); they
+// are added once per task.  1.85 ms.  (Tried and dropped: 8-byte lanes at 4-byte alignment, two
+// rows per instruction -- no faster than one row per instruction.)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair2_kernel(
+__global__ __launch_bounds__(256) void sweep_repack_kernel(const float *__restrict__ B, size_t ldb, uint32_t n,
+                                                           uint32_t d, float *__restrict__ out, uint32_t dp) {
+    const uint32_t q4 = dp / 4;
+    const size_t total = (size_t)n * q4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / q4), c = (uint32_t)(i % q4) * 4;
+        const float *src = B + (size_t)r * ldb + c;
+        float4 v;
+        v.x = c + 0 < d ? src[0] : 0.f;
+        v.y = c + 1 < d ? src[1] : 0.f;
+        v.z = c + 2 < d ? src[2] : 0.f;
+        v.w = c + 3 < d ? src[3] : 0.f;
+        *reinterpret_cast<float4 *>(out + (size_t)r * dp + c) = v;
+    }
+}
+
+// Entries are staged through LDS.  (With the entries in scalar registers, as in the kernels
+// above, picking "my quarter's entry" out of four SGPRs costs ~16 vector ops per quad: 1.90 ms.)
+// The wave copies its stream 128 entries at a time
+// (one coalesced global_load_dwordx4, issued a whole chunk ahead, then one ds_write_b128 into a
+// wave-private 1 KiB slot) and every lane fetches ITS entry of a quad with one broadcast
+// ds_read_b64: no select, no scalar multiply; the run flag / row of the quad's first entry comes
+// from lane 0 (v_readfirstlane).  ~5 vector ops per quad -> the kernel is left with the gather
+// instructions themselves.
+__global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_quad_lds_kernel(
     const SweepTask *__restrict__ tasks, uint32_t task0, uint32_t n_launch,
     const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
     const float *__restrict__ B, uint32_t b_bytes, uint32_t row_bytes, float *__restrict__ C, size_t ldc,
     float *__restrict__ partial, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    __shared__ uint4 ring[kWavesPerBlock][2][64];          // per wave: two slots of 128 entries
     const int lane = threadIdx.x & 63;
     const uint32_t wib = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
     const uint32_t local = blockIdx.x * kWavesPerBlock + wib;
-    if (local >= n_launch) return;
+    if (local >= n_launch) return;                    // no barriers: waves are independent
     const uint32_t t = task0 + local;
     const SweepTask task = tasks[t];
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, b_bytes, 0x00020000);
-    const uint32_t sub = lane & 31;
-    const uint32_t hmask = (lane & 32) ? 0xFFFFFFFFu : 0u;
-
-    for (uint32_t col0 = 0; col0 < d; col0 += 64) {
-        const uint32_t col = col0 + sub * 2;
-        const bool act0 = col < d, act1 = col + 1 < d;      // the second float of the last lane may be past the row:
-        const uint32_t lane_off = (act0 ? col : 0) * 4u;    // it is fetched (inside B or zero-filled by the
-        f32x16 p0, p1;                                      // descriptor's bounds check) and never stored
+    const uint32_t sub = lane & 15, quarter = lane >> 4;
+    const uint32_t col = sub * 4;
+    const bool active = col < d;
+    const uint32_t lane_off = (active ? col : 0) * 4u;
+    f32x16 p0, p1, p2, p3;
 #pragma unroll
-        for (int r = 0; r < 16; r++) { p0[r] = 0.f; p1[r] = 0.f; }
-        uint32_t cur_row = 0;
-        float a0 = 0.f, a1 = 0.f;
+    for (int r = 0; r < 16; r++) { p0[r] = 0.f; p1[r] = 0.f; p2[r] = 0.f; p3[r] = 0.f; }
+    uint32_t cur_row = 0;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 
-        if (task.beg < task.end) {
-            EntryBatch cur = load_batch(entries, task.beg);
-            for (uint32_t e = task.beg; e < task.end; e += 8) {
-                const uint32_t e_next = e + 8 < task.end ? e + 8 : e;
-                const EntryBatch nxt = load_batch(entries, e_next);
-                f32x2_t b[4];
+    const uint32_t n_ent = task.end - task.beg;           // multiple of 16
+    if (n_ent) {
+        const uint4 *stream = reinterpret_cast<const uint4 *>(entries + task.beg) + lane;   // 2 entries per uint4
+        const uint32_t n_chunks = (n_ent + 127) / 128;    // the plan leaves a chunk of slack after the last task
+        ring[wib][0][lane] = stream[0];
+        uint4 pre = stream[n_chunks > 1 ? 64 : 0];
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            ring[wib][(c + 1) & 1][lane] = pre;           // chunk c+1 (slot last read during chunk c-1)
+            pre = stream[(size_t)64 * (c + 2 < n_chunks ? c + 2 : c)];
+            __builtin_amdgcn_wave_barrier();
+            const uint2 *slot = reinterpret_cast<const uint2 *>(&ring[wib][c & 1][0]) + quarter;
+            const uint32_t n_steps = min(8u, (n_ent - c * 128) / 16);
+            for (uint32_t s = 0; s < n_steps; s++) {
+                uint2 ent[4];
+                f32x4_t b[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t off_a = (cur.pk(2 * u) & kColMask) * row_bytes;
-                    const uint32_t off_b = (cur.pk(2 * u + 1) & kColMask) * row_bytes;     // >= off_a
-                    b[u] = mggcn_buffer_load_v2f32(rsrc, (int)(lane_off + ((off_b - off_a) & hmask)), (int)off_a, 0);
+                for (int u = 0; u < 4; u++) ent[u] = slot[s * 16 + u * 4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) b[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (active) {                                    // lanes past the row issue no load (3 % faster)
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        b[u] = mggcn_buffer_load_v4f32(rsrc, (int)(__umul24(ent[u].x & kColMask, row_bytes) + lane_off), 0, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const uint32_t pk = cur.pk(2 * u);
-                    if (pk & kRunFlag) {
-                        p0[cur_row] += a0;
-                        p1[cur_row] += a1;
-                        a0 = 0.f; a1 = 0.f;
+                    const uint32_t pk = __builtin_amdgcn_readfirstlane(ent[u].x);
+                    if (pk & kRunFlag) {                                   // first quad of a (panel,row) run
+                        p0[cur_row] += acc[0];
+                        p1[cur_row] += acc[1];
+                        p2[cur_row] += acc[2];
+                        p3[cur_row] += acc[3];
+                        acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                         cur_row = (pk >> kColBits) & (kRW - 1);
                     }
-                    const uint32_t va = __builtin_bit_cast(uint32_t, cur.val(2 * u));
-                    const uint32_t vb = __builtin_bit_cast(uint32_t, cur.val(2 * u + 1));
-                    const float v = __builtin_bit_cast(float, (va & ~hmask) | (vb & hmask));
-                    a0 = fmaf(v, b[u][0], a0);
-                    a1 = fmaf(v, b[u][1], a1);
+                    const float v = __builtin_bit_cast(float, ent[u].y);
+                    acc[0] = fmaf(v, b[u][0], acc[0]);
+                    acc[1] = fmaf(v, b[u][1], acc[1]);
+                    acc[2] = fmaf(v, b[u][2], acc[2]);
+                    acc[3] = fmaf(v, b[u][3], acc[3]);
                 }
-                cur = nxt;
             }
+            __builtin_amdgcn_wave_barrier();
         }
-        p0[cur_row] += a0;
-        p1[cur_row] += a1;
-
-        auto emit = [&](uint32_t r, float x0, float x1) {
-            x0 += __shfl_xor(x0, 32);
-            x1 += __shfl_xor(x1, 32);
-            if (r >= task.n_rows || !act0 || hmask) return;
-            const uint32_t dst = task_rows[(size_t)t * kRW + r];
-            if (dst & kSlotFlag) {
-                float *pp = partial + (size_t)(dst & ~kSlotFlag) * d + col;
-                pp[0] = x0;
-                if (act1) pp[1] = x1;
-                return;
-            }
-            float *cp = C + (size_t)dst * ldc + col;
-            x0 *= alpha; x1 *= alpha;
-            if (beta != 0.f) { x0 = fmaf(beta, cp[0], x0); if (act1) x1 = fmaf(beta, cp[1], x1); }
-            if (flags & MGGCN_SPMM_LEAKY_RELU) { x0 = lrelu(x0, slope); x1 = lrelu(x1, slope); }
-            cp[0] = x0;
-            if (act1) cp[1] = x1;
-        };
-#define MGGCN_EMIT(R) emit(R, p0[R], p1[R]);
-        MGGCN_EMIT(0) MGGCN_EMIT(1) MGGCN_EMIT(2) MGGCN_EMIT(3) MGGCN_EMIT(4) MGGCN_EMIT(5) MGGCN_EMIT(6) MGGCN_EMIT(7)
-        MGGCN_EMIT(8) MGGCN_EMIT(9) MGGCN_EMIT(10) MGGCN_EMIT(11) MGGCN_EMIT(12) MGGCN_EMIT(13) MGGCN_EMIT(14) MGGCN_EMIT(15)
-#undef MGGCN_EMIT
     }
+    p0[cur_row] += acc[0];
+    p1[cur_row] += acc[1];
+    p2[cur_row] += acc[2];
+    p3[cur_row] += acc[3];
+
+    auto emit = [&](uint32_t r, float x0, float x1, float x2, float x3) {
+        if (r >= task.n_rows) return;                                    // wave-uniform
+        x0 += __shfl_xor(x0, 16); x1 += __shfl_xor(x1, 16); x2 += __shfl_xor(x2, 16); x3 += __shfl_xor(x3, 16);
+        x0 += __shfl_xor(x0, 32); x1 += __shfl_xor(x1, 32); x2 += __shfl_xor(x2, 32); x3 += __shfl_xor(x3, 32);
+        if (!active || quarter) return;
+        const uint32_t dst = task_rows[(size_t)t * kRW + r];
+        const float xs[4] = {x0, x1, x2, x3};
+        if (dst & kSlotFlag) {
+            float *pp = partial + (size_t)(dst & ~kSlotFlag) * d + col;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (col + k < d) pp[k] = xs[k];
+            return;
+        }
+        float *cp = C + (size_t)dst * ldc + col;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (col + k >= d) continue;
+            float o = alpha * xs[k];
+            if (beta != 0.f) o = fmaf(beta, cp[k], o);
+            if (flags & MGGCN_SPMM_LEAKY_RELU) o = lrelu(o, slope);
+            cp[k] = o;
+        }
+    };
+#define MGGCN_EMIT(R) emit(R, p0[R], p1[R], p2[R], p3[R]);
+    MGGCN_EMIT(0) MGGCN_EMIT(1) MGGCN_EMIT(2) MGGCN_EMIT(3) MGGCN_EMIT(4) MGGCN_EMIT(5) MGGCN_EMIT(6) MGGCN_EMIT(7)
+    MGGCN_EMIT(8) MGGCN_EMIT(9) MGGCN_EMIT(10) MGGCN_EMIT(11) MGGCN_EMIT(12) MGGCN_EMIT(13) MGGCN_EMIT(14) MGGCN_EMIT(15)
+#undef MGGCN_EMIT
 }
 
 __global__ __launch_bounds__(256) void sweep_combine_kernel(
@@ -483,9 +533,15 @@ struct VRow {
 
 }  // namespace
 
+uint32_t sweep_panel_rows(uint32_t d_hint) {
+    if (d_hint >= 1 && d_hint <= 64) return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS_NARROW", 16384u));
+    return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 8192u));
+}
+
 struct SweepPlan {
     uint32_t n_rows = 0, n_cols = 0, max_d = 0;
     uint32_t n_tasks = 0, round_tasks = 0, n_split_rows = 0, n_slots = 0;
+    uint32_t run_pad = 2;          // every (panel,row) run is a multiple of this many entries (4: quad form)
     SweepTask *d_tasks = nullptr;
     uint2 *d_entries = nullptr;
     uint32_t *d_task_rows = nullptr;
@@ -495,13 +551,18 @@ struct SweepPlan {
 };
 
 SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
-                            const uint32_t *indices, const float *values, uint32_t max_d, bool force) {
+                            const uint32_t *indices, const float *values, uint32_t max_d, bool force,
+                            uint32_t d_hint) {
     if (!n_rows || !indices || !values) return nullptr;
+    // narrow form (quad kernel): runs padded to 4 entries, tasks to 16, wider panels (the L2
+    // window is counted in bytes: a 176-byte row lets three times as many rows stay resident)
+    const bool narrow = d_hint >= 1 && d_hint <= 64 && n_cols <= (1u << 24);
+    const uint32_t G = narrow ? 4u : 2u, batch_pad = narrow ? 16u : 8u;
     if (n_cols > kColMask) return nullptr;                          // column does not fit the packed entry
     static_assert(kRW == 16, "4 row bits in the packed entry");
     const uint64_t nnz = (uint64_t)indptr[n_rows] - indptr[0];
     if (!force && nnz < env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20)) return nullptr;   // small graphs: row-split is fine
-    const uint32_t panel_rows = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 8192u));
+    const uint32_t panel_rows = sweep_panel_rows(d_hint);
 
     // resident waves per launch ("round").  Registers would admit 6 blocks of 4 waves per CU
     // (56 VGPRs; ~106 SGPRs -> floor(800 / (ceil(sgpr/16)*16 + 16)) = 6, MI355X_MICROARCH.md
@@ -595,7 +656,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
         for (uint32_t t = tid; t < T; t += NT) {
             count_buckets(t, cnt);
             uint64_t len = 0;
-            for (uint32_t c : cnt) len += (c + 1u) & ~1u;
+            for (uint32_t c : cnt) len += (c + G - 1) / G * G;
             plen[t] = len;
         }
     });
@@ -604,7 +665,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     uint64_t off = 0;
     for (uint32_t t = 0; t < T; t++) {
         tasks[t].beg = (uint32_t)off;
-        off += (plen[t] + 7) / 8 * 8;                 // whole 8-entry (64-byte) batches
+        off += (plen[t] + batch_pad - 1) / batch_pad * batch_pad;   // whole 64-byte batches (two per step in the quad form)
         tasks[t].end = (uint32_t)off;
         tasks[t].n_rows = (uint32_t)bins[t].size();
         tasks[t].pad = 0;
@@ -617,7 +678,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
         for (uint32_t t = tid; t < T; t += NT) {
             count_buckets(t, cnt);
             start[0] = 0;
-            for (size_t k = 0; k < n_buckets; k++) start[k + 1] = start[k] + ((cnt[k] + 1u) & ~1u);
+            for (size_t k = 0; k < n_buckets; k++) start[k + 1] = start[k] + (cnt[k] + G - 1) / G * G;
             std::copy(start.begin(), start.begin() + n_buckets, cur.begin());
             uint2 *out = entries.data() + tasks[t].beg;
             const auto &bin = bins[t];
@@ -634,7 +695,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
             for (size_t k = 0; k < n_buckets; k++) {
                 if (!cnt[k]) continue;
                 const uint32_t s0 = start[k], s1 = start[k + 1];
-                if (cnt[k] & 1u) out[s1 - 1] = make_uint2(out[s1 - 2].x, 0u);       // even out the run
+                for (uint32_t q = s0 + cnt[k]; q < s1; q++) out[q] = make_uint2(out[s0 + cnt[k] - 1].x, 0u);   // pad the run
                 for (uint32_t q = s0; q < s1; q += 2)                                // pair: lower column first
                     if ((out[q].x & kColMask) > (out[q + 1].x & kColMask)) std::swap(out[q], out[q + 1]);
                 out[s0].x |= kRunFlag;                                               // first entry of the run
@@ -647,14 +708,15 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
 
     auto *p = new SweepPlan;
     p->n_rows = n_rows; p->n_cols = n_cols; p->max_d = max_d;
-    p->n_tasks = T; p->round_tasks = round_tasks;
+    p->n_tasks = T; p->round_tasks = round_tasks; p->run_pad = G;
     p->n_split_rows = (uint32_t)split_rows.size(); p->n_slots = n_slots;
     const size_t tb = tasks.size() * sizeof(SweepTask), eb = entries.size() * sizeof(uint2);
     const size_t rb = task_rows.size() * sizeof(uint32_t), sb = split_rows.size() * sizeof(SweepSplitRow);
     const size_t pb = (size_t)n_slots * max_d * sizeof(float);
     MGGCN_CHECK_HIP(hipMalloc(&p->d_tasks, tb));
     MGGCN_CHECK_HIP(hipMemcpy(p->d_tasks, tasks.data(), tb, hipMemcpyHostToDevice));
-    MGGCN_CHECK_HIP(hipMalloc(&p->d_entries, std::max<size_t>(eb, 8)));
+    MGGCN_CHECK_HIP(hipMalloc(&p->d_entries, eb + 2048));          // + a chunk: the LDS-staged kernel reads whole 1 KiB chunks
+    MGGCN_CHECK_HIP(hipMemset(reinterpret_cast<char *>(p->d_entries) + eb, 0, 2048));
     if (eb) MGGCN_CHECK_HIP(hipMemcpy(p->d_entries, entries.data(), eb, hipMemcpyHostToDevice));
     MGGCN_CHECK_HIP(hipMalloc(&p->d_task_rows, rb));
     MGGCN_CHECK_HIP(hipMemcpy(p->d_task_rows, task_rows.data(), rb, hipMemcpyHostToDevice));
@@ -690,8 +752,24 @@ bool sweep_supports(const SweepPlan *p, uint32_t d, size_t ldb, size_t ldc, cons
     return true;
 }
 
+bool sweep_wants_repack(const SweepPlan *p, uint32_t d, size_t ldb, const void *B) {
+    if (!p || p->run_pad != 4 || d > 64 || env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) == 0) return false;
+    return !(ldb % 4 == 0 && aligned16(B));
+}
+
+void sweep_repack(hipStream_t st, const float *B, size_t ldb, uint32_t n_cols, uint32_t d, float *out, uint32_t dp) {
+    const size_t total = (size_t)n_cols * (dp / 4);
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, (size_t)kNumCU * 16);
+    hipLaunchKernelGGL(sweep_repack_kernel, dim3(std::max(grid, 1u)), dim3(256), 0, st, B, ldb, n_cols, d, out, dp);
+    MGGCN_CHECK_LAUNCH();
+}
+
 void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb, float *C, size_t ldc,
                   uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    // narrow rows on a quad-padded stream: B must be 16-byte pitched (the caller re-pitches it
+    // with sweep_repack when sweep_wants_repack says so)
+    const bool quad = p->run_pad == 4 && d <= 64 && ldb % 4 == 0 && aligned16(B) &&
+                      env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) != 0;
     // float4 pair form: 16-byte aligned rows of >= 96 columns (narrower rows would idle most of
     // a half-wave); float2 lanes need 8-byte aligned rows; otherwise one column per lane
     const bool vec4 = d >= 96 && d % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C) &&
@@ -702,20 +780,16 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
     const uint32_t row_bytes = (uint32_t)(ldb * sizeof(float));
     // narrow rows (one column per lane, <= 256 B per gather) are instruction-bound rather than
     // L2-window-bound: twice the resident waves per round measured faster (d = 41: 2.4 -> 2.0 ms)
-    // narrow rows: the float2 pair kernel (any alignment)
-    // (measured no faster than the one-column-per-lane kernel at d = 41, 2.2 vs 2.1 ms: that shape is
-    //  bound by scalar issue, ~7 SALU per non-zero, not by gather instructions -> opt-in only)
-    const bool pair2 = !vec4 && d <= 64 && env_u32("MGGCN_SPMM_SWEEP_PAIR2", 0u) != 0;
     const uint32_t per_launch = (vec2 || vec4) ? p->round_tasks : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
     for (uint32_t t0 = 0; t0 < p->n_tasks; t0 += per_launch) {
         const uint32_t n_launch = std::min(per_launch, p->n_tasks - t0);
         const dim3 grid((n_launch + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
-        if (vec4)
-            hipLaunchKernelGGL(spmm_sweep_pair_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
+        if (quad)
+            hipLaunchKernelGGL(spmm_sweep_quad_lds_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
                                alpha, beta, flags, slope);
-        else if (pair2)
-            hipLaunchKernelGGL(spmm_sweep_pair2_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
+        else if (vec4)
+            hipLaunchKernelGGL(spmm_sweep_pair_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
                                alpha, beta, flags, slope);
         else if (vec2)

@@ -304,8 +304,8 @@ class dist_sparse_linear:
         if pl is None:
             ctx.set()
             pl = self.plans[key] = ops.spmm_buffer(
-                ctx.lib, ctx.lib.mggcn_spmm_plan_create(M.n(), M.m(), M.indptr.ctypes.data, M.indices.ctypes.data,
-                                                         M.data.ctypes.data, max(d, 128)))
+                ctx.lib, ctx.lib.mggcn_spmm_plan_create_for(M.n(), M.m(), M.indptr.ctypes.data, M.indices.ctypes.data,
+                                                             M.data.ctypes.data, max(d, 128), d))
         return pl
 
     def _run(self, dctx: dist_context, A: dist_row_csr_matrix, tag: str, B: dist_row_dn_matrix,

@@ -27,8 +27,8 @@ spmm_buffer get_matmul_buffer(const context ctx, const csr_matrix<x_t, v_t, r_t>
                               const dn_matrix<r_t> C, const r_t = 1, const r_t = 0) {
     mggcn_require(A.m() == B.n() && A.n() == C.n() && B.m() == C.m(), "get_matmul_buffer: shape mismatch");
     ctx.set();
-    return spmm_buffer(mggcn_spmm_plan_create(A.n(), A.m(), A.indptr().data(), A.indices().data(), A.data().data(),
-                                              (uint32_t)std::max<std::size_t>(B.m(), 128)),
+    return spmm_buffer(mggcn_spmm_plan_create_for(A.n(), A.m(), A.indptr().data(), A.indices().data(), A.data().data(),
+                                                  (uint32_t)std::max<std::size_t>(B.m(), 128), (uint32_t)B.m()),
                        &mggcn_spmm_plan_destroy);
 }
 
@@ -75,14 +75,16 @@ dist_spmm_buffers get_matmul_buffer(const dist_context ctx, const dist_row_csr_m
         for (std::size_t i = 0; i < P; i++)
             if (rounds || i == j) {
                 const auto blk = A[{j, i}];
-                out.block[j][i] = spmm_buffer(mggcn_spmm_plan_create(blk.n(), blk.m(), blk.indptr().data(), blk.indices().data(),
-                                                                     blk.data().data(), (uint32_t)std::max<std::size_t>(B.m(), 128)),
+                out.block[j][i] = spmm_buffer(mggcn_spmm_plan_create_for(blk.n(), blk.m(), blk.indptr().data(), blk.indices().data(),
+                                                                         blk.data().data(), (uint32_t)std::max<std::size_t>(B.m(), 128),
+                                                                         (uint32_t)B.m()),
                                               &mggcn_spmm_plan_destroy);
             }
         if (!rounds) {
             const auto &rem = A.remote(j);
-            out.remote.push_back(spmm_buffer(mggcn_spmm_plan_create(rem.n(), rem.m(), rem.indptr().data(), rem.indices().data(),
-                                                                    rem.data().data(), (uint32_t)std::max<std::size_t>(B.m(), 128)),
+            out.remote.push_back(spmm_buffer(mggcn_spmm_plan_create_for(rem.n(), rem.m(), rem.indptr().data(), rem.indices().data(),
+                                                                        rem.data().data(), (uint32_t)std::max<std::size_t>(B.m(), 128),
+                                                                        (uint32_t)B.m()),
                                              &mggcn_spmm_plan_destroy));
         }
     }

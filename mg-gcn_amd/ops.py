@@ -44,8 +44,8 @@ def get_matmul_buffer(ctx: context, A: csr_matrix, B: dn_matrix, C: dn_matrix, a
     _req(A.m() == B.n(), "A.m() != B.n()")
     _req(A.n() == C.n() and B.m() == C.m(), "C shape mismatch")
     ctx.set()
-    h = ctx.lib.mggcn_spmm_plan_create(A.n(), A.m(), A.indptr.ctypes.data, A.indices.ctypes.data,
-                                       A.data.ctypes.data, max(int(max_d or 0), B.m()))
+    h = ctx.lib.mggcn_spmm_plan_create_for(A.n(), A.m(), A.indptr.ctypes.data, A.indices.ctypes.data,
+                                           A.data.ctypes.data, max(int(max_d or 0), B.m()), B.m())
     return spmm_buffer(ctx.lib, h)
 
 

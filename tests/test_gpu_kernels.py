@@ -266,6 +266,7 @@ def force_sweep(monkeypatch):
     and a tiny panel so that the (panel, row) ordering of the entry streams is exercised."""
     monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_NNZ", "1")
     monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS", "64")
+    monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS_NARROW", "96")
     monkeypatch.setenv("MGGCN_SPMM_SLICE_ROWS", "400")        # several column slices (beta chaining)
     monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_RUN_X10", "0")   # sparse test rows would be sent to row-split
     monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
@@ -308,6 +309,34 @@ def test_sweep_spmm_edge_cases_and_reproducibility(pkg, oracle, ctx, force_sweep
         assert (got[[0, 5, 10, 11]] == 0).all()
         again, _ = _run_spmm(pkg, ctx, A, B, C0, 1.0, 0.0)
         np.testing.assert_array_equal(got, again)                  # fixed fold order -> bitwise equal
+
+
+@pytest.mark.parametrize("d_hint,d", [(41, 128), (41, 24), (41, 44), (128, 41), (16, 41), (64, 64), (3, 3)])
+def test_sweep_plan_hint_only_picks_the_fast_form(pkg, oracle, ctx, force_sweep, d_hint, d):
+    """mggcn_spmm_plan_create_for: a plan built for narrow rows (runs padded to four entries, B
+    re-pitched through the plan's scratch when its pitch is not 16-byte) serves wide calls and
+    the other way round; widths above the scratch fall back to the one-column-per-lane kernel."""
+    n = 1200
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 50_000, 3000, seed=7)
+    dv = np.random.default_rng(7).standard_normal(dv.shape[0]).astype(np.float32)
+    A, Ao = _csr(pkg, oracle, ip, ix, dv, n)
+    rng = np.random.default_rng(d_hint * 1000 + d)
+    B = rng.standard_normal((n, d), dtype=np.float32)
+    C0 = rng.standard_normal((n, d), dtype=np.float32)
+    ctx.set()
+    h = ctx.lib.mggcn_spmm_plan_create_for(A.n(), A.m(), A.indptr.ctypes.data, A.indices.ctypes.data,
+                                           A.data.ctypes.data, 128, d_hint)
+    buf = pkg.ops.spmm_buffer(ctx.lib, h)
+    assert buf.num_sweep_tasks() > 0
+    for alpha, beta, flags in [(1.0, 0.0, 0), (0.5, 2.0, 1)]:
+        Bd, Cd = pkg.dn_matrix.from_numpy(B), pkg.dn_matrix.from_numpy(C0)
+        pkg.matmul(ctx, A, Bd, Cd, buf, alpha, beta, flags)
+        ctx.sync()
+        want = oracle.spmm(Ao, B, C0.copy(), alpha, beta, f64acc=True)
+        if flags:
+            want = oracle.leaky_relu_forward(want)
+        assert rowwise_relerr(Cd.numpy(), want) <= TOL, (d_hint, d, alpha, beta)
+        np.testing.assert_array_equal(Bd.numpy(), B)          # the re-pitch never writes the caller's B
 
 
 def test_sweep_equals_rowsplit_on_a_big_graph(pkg, ctx, monkeypatch):
