@@ -327,9 +327,9 @@ class dist_sparse_linear:
             last_local = flags if P == 1 else 0
             ops._spmm(ctx, A.diag, B.local, C.local, self._plan(ctx, (tag, "diag"), A.diag, d), 1.0, beta,
                       last_local)
+            pend.wait(0)                                       # also at P == 1: the buffer is reused by the next call
+            ctx.record(name + "0_matmul-bcast-finish", 0)
             if P > 1:
-                pend.wait(0)
-                ctx.record(name + "0_matmul-bcast-finish", 0)
                 ops._spmm(ctx, A.remote, gathered, C.local, self._plan(ctx, (tag, "remote"), A.remote, d), 1.0,
                           1.0, flags)
         else:  # reference schedule: round i = broadcast shard i || SpMM with block (r, i)
