@@ -19,7 +19,10 @@ src/cuda_utils.hpp:61-89).  Two modes:
     every GPU pushes to all 7 peers at once -- while the compute stream already
     multiplies the local diagonal block A[j,j] (needs no communication); the
     remaining P-1 blocks are pre-merged at partition time into one CSR with global
-    column indices and run as a single SpMM over the gathered buffer (beta = 1).
+    column indices and run over the gathered buffer (beta = 1).  For P > 2 the exchange
+    is cut into K pieces of every shard (K all-gathers queued back to back, the remote
+    block cut by piece with renumbered columns): the SpMM over piece c overlaps the
+    transfer of piece c+1.
     C_j = A[j,j].B_j + sum_{i!=j} A[j,i].B_i  -- the reference's sum, regrouped.
 ``rounds``: the reference's schedule, one broadcast + one block SpMM per round i,
     double-buffered, accumulating in round order (used for order-exact parity tests
@@ -101,6 +104,49 @@ def split_local_remote(A: csr_matrix, row_begin: int, row_end: int) -> Tuple[csr
     indices[rpos] = right.indices + np.uint32(row_end)
     data[rpos] = right.data
     return diag, csr_matrix(indptr.astype(np.uint32), indices, data, n)
+
+
+def default_chunks(P: int) -> int:
+    """Pieces the exchange of one SpMM is cut into (all-gather mode).  With one piece only the
+    diagonal block (1/P of the work) overlaps the exchange; with K pieces the SpMM over piece c
+    runs while piece c+1 is still on the wire.  P <= 2: the diagonal block already covers the
+    transfer.  Override with MGGCN_DIST_CHUNKS."""
+    import os
+    env = os.environ.get("MGGCN_DIST_CHUNKS")
+    if env:
+        return max(1, int(env))
+    return 1 if P <= 2 else (2 if P <= 4 else 4)
+
+
+def chunk_bounds(rows: int, K: int) -> List[int]:
+    return [c * rows // K for c in range(K + 1)]
+
+
+def split_remote_chunks(remote: csr_matrix, P: int, rows: int, K: int) -> List[csr_matrix]:
+    """Cuts the merged remote block (global column g = s*rows + i: row i of rank s's shard) into
+    K matrices by the PIECE of the shard the column lives in, i in [cb[c], cb[c+1]), and renumbers
+    the columns to the layout one all-gather of that piece produces: s*len_c + (i - cb[c]).
+    sum_c remote_c . gathered_c == remote . gathered  (same products, regrouped)."""
+    cb = np.asarray(chunk_bounds(rows, K), dtype=np.int64)
+    if K == 1:
+        return [remote]
+    ip = remote.indptr.astype(np.int64)
+    g = remote.indices.astype(np.int64)
+    src, i = g // rows, g % rows
+    cid = np.searchsorted(cb, i, side="right") - 1
+    row_ids = np.repeat(np.arange(remote.n(), dtype=np.int64), np.diff(ip))
+    counts = np.bincount(cid * remote.n() + row_ids, minlength=K * remote.n()).reshape(K, remote.n())
+    order = np.argsort(cid, kind="stable")                 # grouped by piece, CSR order kept inside
+    new_col = (src * (cb[cid + 1] - cb[cid]) + (i - cb[cid])).astype(np.uint32)
+    out, at = [], 0
+    for c in range(K):
+        nz = int(counts[c].sum())
+        sel = order[at:at + nz]
+        at += nz
+        indptr = np.zeros(remote.n() + 1, dtype=np.int64)
+        np.cumsum(counts[c], out=indptr[1:])
+        out.append(csr_matrix(indptr.astype(np.uint32), new_col[sel], remote.data[sel], int(P * (cb[c + 1] - cb[c]))))
+    return out
 
 
 # --------------------------------------------------------------------------------------
@@ -276,13 +322,19 @@ class dist_row_csr_matrix:
     builds only ITS row of blocks, plus the (diagonal, merged-remote) pair used by the
     all-gather schedule."""
 
-    def __init__(self, dctx: dist_context, A: csr_matrix, p: Sequence[int], q: Sequence[int]):
+    def __init__(self, dctx: dist_context, A: csr_matrix, p: Sequence[int], q: Sequence[int],
+                 chunks: Optional[int] = None):
         assert list(p) == list(q), "the reference only ever passes p == q (src/main.cpp:148-149)"
         self.N_, self.M_ = A.n(), A.m()
         self.p = list(p)
         r = dctx.rank
         self.blocks = split_row_block(A, p[r], p[r + 1], q)               # A[{r, j}]
         self.diag, self.remote = split_local_remote(A, p[r], p[r + 1])
+        rows = p[r + 1] - p[r]
+        K = default_chunks(dctx.P) if chunks is None else int(chunks)
+        K = max(1, min(K, rows))
+        self.chunk_bounds = chunk_bounds(rows, K)
+        self.remote_chunks = split_remote_chunks(self.remote, dctx.P, rows, K)
 
     def n(self): return self.N_
     def m(self): return self.M_
@@ -320,18 +372,26 @@ class dist_sparse_linear:
         ctx.record(name + "0_matmul-spmm", 0)
         ctx.wait(name + "0_matmul-spmm", 1)                    # comm stream sees the producer of B
         if self.mode == "allgather":
-            gathered = dn_matrix(rows * P, d, self.bcast[0])
+            # the exchange, cut into K pieces of the shard (rows cb[c]..cb[c+1] of every rank): all K
+            # all-gathers are queued on the comm stream at once and land one after the other
+            cb, K = A.chunk_bounds, len(A.remote_chunks)
             ctx.record(name + "0_matmul-bcast-start", cs)
-            pend = dctx.all_gather_rows(B.local.t, gathered.t, cs)
+            pend, gathered = [], []
+            for c in range(K):
+                g = dn_matrix(P * (cb[c + 1] - cb[c]), d, self.bcast[0][P * cb[c] * d:])
+                gathered.append(g)
+                pend.append(dctx.all_gather_rows(B.local.t[cb[c]:cb[c + 1]], g.t, cs))
             # local block first: no dependency on the exchange
             last_local = flags if P == 1 else 0
             ops._spmm(ctx, A.diag, B.local, C.local, self._plan(ctx, (tag, "diag"), A.diag, d), 1.0, beta,
                       last_local)
-            pend.wait(0)                                       # also at P == 1: the buffer is reused by the next call
-            ctx.record(name + "0_matmul-bcast-finish", 0)
-            if P > 1:
-                ops._spmm(ctx, A.remote, gathered, C.local, self._plan(ctx, (tag, "remote"), A.remote, d), 1.0,
-                          1.0, flags)
+            for c in range(K):                                 # piece c multiplies while piece c+1 is on the wire
+                pend[c].wait(0)                                # also at P == 1: the buffer is reused by the next call
+                ctx.record(name + f"{c}_matmul-bcast-finish", 0)
+                if P > 1:
+                    blk = A.remote_chunks[c]
+                    ops._spmm(ctx, blk, gathered[c], C.local, self._plan(ctx, (tag, "remote", c), blk, d), 1.0,
+                              1.0, flags if c == K - 1 else 0)
         else:  # reference schedule: round i = broadcast shard i || SpMM with block (r, i)
             bufs = [dn_matrix(rows, d, self.bcast[0]), dn_matrix(rows, d, self.bcast[1])]
             for i in range(P):

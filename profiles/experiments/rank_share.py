@@ -40,3 +40,15 @@ for P in (1, 2, 4, 8):
     base = base or ms
     print(f"P={P}: rank-0 SpMM {ms:.3f} ms  (ideal {base/P:.3f}, efficiency {base/P/ms*100:.0f} %)  "
           f"diag nnz {diag.nnz()} tasks {pd.num_sweep_tasks()}  remote nnz {remote.nnz() if P>1 else 0} tasks {pr.num_sweep_tasks() if pr else 0}", flush=True)
+    # the exchange cut into K pieces (dist.split_remote_chunks): K smaller remote SpMMs instead of one
+    for K in ((2, 4) if P >= 4 else ()):
+        cb = D.chunk_bounds(rows, K)
+        chunks = D.split_remote_chunks(remote, P, rows, K)
+        Bs = [pkg.dn_matrix(P * (cb[c + 1] - cb[c]), d, Ball.t.view(-1)[P * cb[c] * d:]) for c in range(K)]
+        plans = [pkg.get_matmul_buffer(ctx, chunks[c], Bs[c], C) for c in range(K)]
+        def run_k():
+            pkg.matmul(ctx, diag, B0, C, pd, 1.0, 0.0)
+            for c in range(K):
+                pkg.matmul(ctx, chunks[c], Bs[c], C, plans[c], 1.0, 1.0)
+        msk = timeit(run_k)
+        print(f"      K={K} pieces: {msk:.3f} ms ({msk/ms*100-100:+.0f} % vs one remote SpMM)  tasks/piece {plans[0].num_sweep_tasks()}", flush=True)

@@ -54,6 +54,18 @@ def _worker(rank, P, port, n, d, out_q):
         C = orc.spmm(as_o(diag), mine.numpy())
         orc.spmm(as_o(remote), gathered, C, 1.0, 1.0)
 
+        # the same exchange cut into K pieces of every shard (K all-gathers; remote block cut by piece)
+        rows = p[rank + 1] - p[rank]
+        Cc = {}
+        for K in (2, 3):
+            cb = D.chunk_bounds(rows, K)
+            acc = orc.spmm(as_o(diag), mine.numpy())
+            for c, blk in enumerate(D.split_remote_chunks(remote, P, rows, K)):
+                piece = D.gloo_all_gather_rows(mine[cb[c]:cb[c + 1]].contiguous(), P).numpy()
+                assert piece.shape == (P * (cb[c + 1] - cb[c]), d) and blk.m() == piece.shape[0]
+                orc.spmm(as_o(blk), piece, acc, 1.0, 1.0)
+            Cc[K] = acc
+
         # the reference's rounds: broadcast shard i, multiply block (rank, i), accumulate in order
         R = np.empty_like(C)
         for i in range(P):
@@ -64,7 +76,7 @@ def _worker(rank, P, port, n, d, out_q):
         G = rng.standard_normal((n, 5)).astype(np.float32)
         gw = torch.from_numpy(orc.gemm(B[p[rank]:p[rank + 1]], G[p[rank]:p[rank + 1]], A_T=True))
         gw = D.gloo_all_reduce_sum(gw.reshape(-1)).reshape(d, 5).numpy()
-        out_q.put((rank, C, R, gw))
+        out_q.put((rank, C, R, gw, Cc))
     finally:
         dist.destroy_process_group()
 
@@ -96,8 +108,10 @@ def test_partition_and_exchange_match_single_process(oracle, pkg, P):
     G.standard_normal((n, d))
     Gm = G.standard_normal((n, 5)).astype(np.float32)
     gw_full = oracle.gemm(B, Gm, A_T=True, f64acc=True)
-    for rank, C, R, gw in res:
+    for rank, C, R, gw, Cc in res:
         np.testing.assert_allclose(C, full[p[rank]:p[rank + 1]], rtol=1e-5, atol=1e-6)     # regrouped sum
+        for K in (2, 3):
+            np.testing.assert_allclose(Cc[K], full[p[rank]:p[rank + 1]], rtol=1e-5, atol=1e-6)
         np.testing.assert_array_equal(R, rounds[rank])                                      # same order: bit-exact
         np.testing.assert_allclose(gw, gw_full, rtol=1e-5, atol=1e-5)
 
@@ -120,3 +134,28 @@ def test_local_remote_split_reassembles(pkg, oracle):
             assert diag.nnz() + remote.nnz() == int(A.indptr[p[r + 1]] - A.indptr[p[r]])
     with pytest.raises(ValueError):
         D.partition_bounds(10, 4)            # n % P != 0 (reference asserts, dist_matrix.hpp:428)
+
+
+def test_remote_chunks_reassemble(pkg):
+    """split_remote_chunks: piece c of the remote block, with the columns renumbered to the layout
+    an all-gather of piece c of every shard produces, holds exactly the entries of those columns."""
+    D = pkg.dist
+    n = 60
+    ip, ix, dv = _graph(n, 9)
+    A = pkg.csr_matrix(ip, ix, dv, n)
+    for P in (2, 3, 4):
+        p = D.partition_bounds(n, P)
+        rows = n // P
+        for r in range(P):
+            _, remote = D.split_local_remote(A, p[r], p[r + 1])
+            dense = remote.as_dn()
+            for K in (1, 2, 4, 7, rows):
+                cb = D.chunk_bounds(rows, K)
+                chunks = D.split_remote_chunks(remote, P, rows, K)
+                assert len(chunks) == K and sum(c.nnz() for c in chunks) == remote.nnz()
+                for c, blk in enumerate(chunks):
+                    ln = cb[c + 1] - cb[c]
+                    assert (blk.n(), blk.m()) == (rows, P * ln)
+                    cols = np.concatenate([np.arange(s * rows + cb[c], s * rows + cb[c + 1]) for s in range(P)])
+                    np.testing.assert_array_equal(blk.as_dn(), dense[:, cols])
+    assert D.default_chunks(1) == 1 and D.default_chunks(2) == 1 and D.default_chunks(8) >= 2

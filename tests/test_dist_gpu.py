@@ -30,7 +30,7 @@ def _data(n, F, C):
     return pkg, (ip, ix, dv), X, Y
 
 
-def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo"):
+def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo", chunks=None):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":
@@ -48,8 +48,8 @@ def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo"):
         A_T = A.transpose()
         p = D.partition_bounds(n, P)
         sizes = [F] + hidden + [(C + P - 1) // P * P]
-        G = D.dist_gcn(dctx, D.dist_row_csr_matrix(dctx, A, p, p), D.dist_row_csr_matrix(dctx, A_T, p, p), sizes,
-                       fused=True, mode=mode)
+        G = D.dist_gcn(dctx, D.dist_row_csr_matrix(dctx, A, p, p, chunks), D.dist_row_csr_matrix(dctx, A_T, p, p, chunks),
+                       sizes, fused=True, mode=mode)
         Xd, Yd = D.dist_row_dn_matrix(dctx, X), D.dist_row_dn_matrix(dctx, Y)
         out = []
         for _ in range(epochs):
@@ -64,13 +64,15 @@ def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("P,mode", [(2, "allgather"), (2, "rounds"), (3, "allgather")])
-def test_dist_gcn_matches_oracle(oracle, P, mode):
+@pytest.mark.parametrize("P,mode,chunks", [(2, "allgather", None), (2, "rounds", None), (3, "allgather", None),
+                                           (2, "allgather", 3), (4, "allgather", 2)])
+def test_dist_gcn_matches_oracle(oracle, P, mode, chunks):
     n, F, C, hidden, epochs = 1536, 20, 5, [16, 16], 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, P, port, n, F, C, hidden, mode, epochs, q)) for r in range(P)]
+    procs = [ctx.Process(target=_worker, args=(r, P, port, n, F, C, hidden, mode, epochs, q, "gloo", chunks))
+             for r in range(P)]
     for pr in procs:
         pr.start()
     res = sorted([q.get(timeout=300) for _ in range(P)], key=lambda t: t[0])
@@ -106,7 +108,7 @@ def test_dist_gcn_over_rccl_single_rank(oracle, mode):
     n, F, C, hidden, epochs = 1536, 20, 5, [16, 16], 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    pr = ctx.Process(target=_worker, args=(0, 1, _free_port(), n, F, C, hidden, mode, epochs, q, "nccl"))
+    pr = ctx.Process(target=_worker, args=(0, 1, _free_port(), n, F, C, hidden, mode, epochs, q, "nccl", 2))
     pr.start()
     rank, out, W = q.get(timeout=300)
     pr.join(timeout=60)
