@@ -255,6 +255,23 @@ class dist_context:
                 off += t.numel()
 
 
+    def all_reduce_sum_async(self, flat, after_stream_id: int = 0):
+        """In-place sum over ranks of ONE flat tensor on the comm stream, ordered after the work
+        already queued on ``after_stream_id``; returns a handle whose .wait(stream_id) orders the
+        result before later work on that stream.  The compute stream keeps going meanwhile."""
+        torch, dist = _torch(), _dist()
+        cs = self.bcast_stream_id()
+        if self._nccl():
+            if cs != after_stream_id:
+                self.ctx.record("__allreduce-ready", after_stream_id)
+                self.ctx.wait("__allreduce-ready", cs)
+            with torch.cuda.stream(self.ctx.cuda_streams[cs]):
+                work = dist.all_reduce(flat, group=self.group, async_op=True)
+            return _Pending(self, work, None, None)
+        self.ctx.cuda_streams[after_stream_id].synchronize()
+        return _Pending(self, None, gloo_all_reduce_sum(flat.detach().cpu(), self.group), flat)
+
+
 class _Pending:
     def __init__(self, dctx, work, host, out):
         self.dctx, self.work, self.host, self.out = dctx, work, host, out
@@ -422,8 +439,17 @@ class dist_row_linear:
     def __init__(self, dctx: dist_context, name: str, in_: int, out: int, backward_out: bool = True,
                  fused: bool = False):
         self.name = name
-        self.W, self.G_W = repl_dn_matrix(dctx, in_, out), repl_dn_matrix(dctx, in_, out)
-        self.b, self.G_b = repl_dn_matrix(dctx, 1, out), repl_dn_matrix(dctx, 1, out)
+        self.W, self.b = repl_dn_matrix(dctx, in_, out), repl_dn_matrix(dctx, 1, out)
+        # G_W and G_b live in ONE buffer: a single in-place all-reduce, no packing copies
+        off_b = (in_ * out + 3) // 4 * 4                       # keep G_b 16-byte aligned
+        self.G_flat = _torch().empty(off_b + out, dtype=_torch().float32, device=dctx.ctx.device)
+        self.G_W = repl_dn_matrix.__new__(repl_dn_matrix)
+        self.G_W.local = dn_matrix(in_, out, self.G_flat)
+        self.G_b = repl_dn_matrix.__new__(repl_dn_matrix)
+        self.G_b.local = dn_matrix(1, out, self.G_flat[off_b:])
+        if off_b != in_ * out:
+            self.G_flat.zero_()                                # the padding takes part in the sum
+        self._grad_pending = None
         self.backward_out, self.fused = backward_out, fused
         self.W.init(dctx)
         self.b.init(dctx, _SQRT_1_3)
@@ -453,15 +479,23 @@ class dist_row_linear:
         ctx.record(n + "1_0_matmul-gemm", 0)
         ops.matmul(ctx, self.ones, G.local, self.G_b.local, 1.0, 0.0)
         ops.matmul(ctx, self.X.local, G.local, self.G_W.local, 1.0, 0.0, True)
-        dctx.all_reduce_sum([self.G_W.local.t, self.G_b.local.t])
+        # summed over ranks on the comm stream while the backward pass goes on; awaited by
+        # finish_backward() (end of dist_gcn.backward) / adam_update
+        self._grad_pending = dctx.all_reduce_sum_async(self.G_flat, 0)
         ctx.record(n + "1_2_matmul-gemm", 0)
         if self.backward_out:
             ops.matmul(ctx, G.local, self.W.local, G_out.local, 1.0, 0.0 if discard else 1.0, False, True)
         ctx.record(n + "1_3_matmul-gemm", 0)
         ctx.register_timer(n + "1_matmul-gemm", n + "1_0_matmul-gemm", n + "1_3_matmul-gemm")
 
+    def finish_backward(self, dctx: dist_context) -> None:
+        if self._grad_pending is not None:
+            self._grad_pending.wait(0)
+            self._grad_pending = None
+
     def adam_update(self, dctx: dist_context, lr, beta1, beta2, weight_decay, eps) -> None:
         ctx = dctx.ctx
+        self.finish_backward(dctx)
         if self.mW is None:
             self.mW, self.vW = repl_dn_matrix(dctx, self.W.shape()), repl_dn_matrix(dctx, self.W.shape())
             self.mb, self.vb = repl_dn_matrix(dctx, self.b.shape()), repl_dn_matrix(dctx, self.b.shape())
@@ -562,6 +596,9 @@ class dist_gcn_layer:
             return self.G_out
         return self.G_HW
 
+    def finish_backward(self, dctx) -> None:
+        self.lin.finish_backward(dctx)
+
     def adam_update(self, dctx, lr, beta1, beta2, weight_decay, eps):
         self.lin.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
 
@@ -642,6 +679,8 @@ class dist_gcn:
         G = self.loss_layer.backward()
         for layer in reversed(self.layers_):
             G = layer.backward(dctx, G)
+        for layer in self.layers_:                 # gradients are summed over ranks from here on
+            layer.finish_backward(dctx)
 
     def adam_update(self, dctx, lr, beta1, beta2, weight_decay, eps) -> None:
         for layer in self.layers_:

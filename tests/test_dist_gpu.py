@@ -55,6 +55,7 @@ def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo", chu
         for _ in range(epochs):
             loss, acc = G.train_forward(dctx, Xd, Yd)
             G.backward(dctx)
+            dctx.sync()
             grads = [l.GW().local.numpy().copy() for l in G.layers()]
             G.adam_update(dctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
             dctx.sync()
