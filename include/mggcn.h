@@ -151,6 +151,13 @@ size_t mggcn_gemm_workspace_bytes(int trans_a, int trans_b, uint32_t M, uint32_t
 void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
                     uint32_t K, float alpha, const float *A, size_t lda, const float *B, size_t ldb,
                     float beta, float *C, size_t ldc, void *workspace, size_t workspace_bytes);
+/* C = alpha * op(A) * op(B) + 1 * bias^T   (bias: N floats added to every row of C).
+ * The reference's linear forward is broadcast_rows(b -> XW) followed by an sgemm with beta = 1
+ * (src/gcn.hpp:116-123); this is the same sum in one pass: no broadcast kernel, no read of C.
+ * Workspace as for mggcn_gemm_f32. */
+void mggcn_gemm_bias_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
+                         uint32_t K, float alpha, const float *A, size_t lda, const float *B, size_t ldb,
+                         const float *bias, float *C, size_t ldc, void *workspace, size_t workspace_bytes);
 
 /* ======================================================================== *
  * Element-wise / row kernels: one entry point per live launcher of

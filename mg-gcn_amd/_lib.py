@@ -58,6 +58,8 @@ PROTOTYPES = {
     "mggcn_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_uint32, c_uint32, c_uint32]),
     "mggcn_gemm_f32": (None, [vp, c_int, c_int, c_uint32, c_uint32, c_uint32, c_float, vp, c_size_t, vp,
                               c_size_t, c_float, vp, c_size_t, vp, c_size_t]),
+    "mggcn_gemm_bias_f32": (None, [vp, c_int, c_int, c_uint32, c_uint32, c_uint32, c_float, vp, c_size_t, vp,
+                                   c_size_t, vp, vp, c_size_t, vp, c_size_t]),
     "mggcn_leaky_relu_forward_f32": (None, [vp, vp, vp, c_size_t, c_float]),
     "mggcn_leaky_relu_backward_f32": (None, [vp, vp, vp, vp, c_size_t, c_float]),
     "mggcn_broadcast_rows_f32": (None, [vp, vp, vp, c_size_t, c_size_t, c_int]),

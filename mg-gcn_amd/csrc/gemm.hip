@@ -103,7 +103,7 @@ template <bool A_KCONTIG, bool B_KCONTIG, int BN>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(
     uint32_t M, uint32_t N, uint32_t K, float alpha, const float *__restrict__ A, size_t lda,
     const float *__restrict__ B, size_t ldb, float beta, float *__restrict__ C, size_t ldc,
-    float *__restrict__ slab, uint32_t k_chunk, bool a_vec, bool b_vec) {
+    float *__restrict__ slab, uint32_t k_chunk, bool a_vec, bool b_vec, const float *__restrict__ bias) {
     constexpr int WN = BN == 128 ? 2 : 1;           // waves along N
     constexpr int WM = 4 / WN;                      // waves along M
     constexpr int MI = BM / WM / 32;                // MFMA blocks per wave along M (2 or 1)
@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(
                         slab[((size_t)blockIdx.z * M + row) * N + col] = v;
                     } else {
                         float *cp = C + (size_t)row * ldc + col;
-                        *cp = beta == 0.f ? alpha * v : fmaf(beta, *cp, alpha * v);
+                        // bias: the row vector the reference broadcasts into C before its beta = 1 sgemm
+                        // (src/gcn.hpp:116-123); same single rounding as fmaf(1, bias, alpha*v)
+                        if (bias) *cp = fmaf(1.f, bias[col], alpha * v);
+                        else *cp = beta == 0.f ? alpha * v : fmaf(beta, *cp, alpha * v);
                     }
                 }
             }
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float *__restrict__ slab,
                                                                  uint32_t splits, uint32_t M, uint32_t N,
                                                                  float alpha, float beta,
-                                                                 float *__restrict__ C, size_t ldc) {
+                                                                 float *__restrict__ C, size_t ldc,
+                                                                 const float *__restrict__ bias) {
     __shared__ float part[8][33];
     const uint32_t total = M * N;                    // < 2^32: checked by the launcher
     const uint32_t lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -207,7 +211,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float *__
 #pragma unroll
             for (int g = 1; g < 8; g++) t += part[g][lane];
             float *cp = C + (size_t)(i / N) * ldc + (i % N);
-            *cp = beta == 0.f ? alpha * t : fmaf(beta, *cp, alpha * t);
+            if (bias) *cp = fmaf(1.f, bias[i % N], alpha * t);
+            else *cp = beta == 0.f ? alpha * t : fmaf(beta, *cp, alpha * t);
         }
         __syncthreads();
     }
@@ -311,10 +316,38 @@ MGGCN_API size_t mggcn_gemm_workspace_bytes(int trans_a, int trans_b, uint32_t M
     return s.splits > 1 ? (size_t)s.splits * M * N * sizeof(float) : 0;
 }
 
+namespace {
+void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N, uint32_t K, float alpha,
+                   const float *A, size_t lda, const float *B, size_t ldb, float beta, float *C, size_t ldc,
+                   void *workspace, size_t workspace_bytes, const float *bias);
+}
+
 MGGCN_API void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
                               uint32_t K, float alpha, const float *A, size_t lda, const float *B,
                               size_t ldb, float beta, float *C, size_t ldc, void *workspace,
                               size_t workspace_bytes) {
+    gemm_dispatch(stream, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, workspace, workspace_bytes,
+                  nullptr);
+}
+
+MGGCN_API void mggcn_gemm_bias_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
+                                   uint32_t K, float alpha, const float *A, size_t lda, const float *B,
+                                   size_t ldb, const float *bias, float *C, size_t ldc, void *workspace,
+                                   size_t workspace_bytes) {
+    MGGCN_REQUIRE(bias != nullptr, "mggcn_gemm_bias_f32 needs a bias row");
+    if (M && N && !K) {          // degenerate: C = 1 bias^T
+        MGGCN_REQUIRE(ldc == N, "K == 0 with a bias needs a dense C");
+        mggcn_broadcast_rows_f32(stream, bias, C, (size_t)M * N, N, 1);
+        return;
+    }
+    gemm_dispatch(stream, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, workspace, workspace_bytes,
+                  bias);
+}
+
+namespace {
+void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N, uint32_t K, float alpha,
+                   const float *A, size_t lda, const float *B, size_t ldb, float beta, float *C, size_t ldc,
+                   void *workspace, size_t workspace_bytes, const float *bias) {
     if (!M || !N) return;
     hipStream_t st = as_stream(stream);
     MGGCN_REQUIRE(C != nullptr && ldc >= N, "bad C / ldc");
@@ -337,7 +370,7 @@ MGGCN_API void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, u
                            lda, B, ldb, slab, sp.k_chunk, M);
         MGGCN_CHECK_LAUNCH();
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(std::min<unsigned>((M * N + 31) / 32, 2048u)), dim3(256), 0,
-                           st, slab, sp.splits, M, N, alpha, beta, C, ldc);
+                           st, slab, sp.splits, M, N, alpha, beta, C, ldc, bias);
         MGGCN_CHECK_LAUNCH();
         return;
     }
@@ -356,7 +389,7 @@ MGGCN_API void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, u
 
 #define MGGCN_GEMM_LAUNCH(AK, BKC, BNV)                                                               \
     hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKC, BNV>), grid, block, 0, st, M, N, K, alpha, A, lda, B, ldb, \
-                       beta, C, ldc, slab, sp.k_chunk, a_vec, b_vec)
+                       beta, C, ldc, slab, sp.k_chunk, a_vec, b_vec, bias)
     if (bn == 128) {
         if (a_kc && b_kc) MGGCN_GEMM_LAUNCH(true, true, 128);
         else if (a_kc) MGGCN_GEMM_LAUNCH(true, false, 128);
@@ -372,7 +405,8 @@ MGGCN_API void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, u
     MGGCN_CHECK_LAUNCH();
     if (sp.splits > 1) {
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(std::min<unsigned>((M * N + 31) / 32, 2048u)), dim3(256), 0,
-                           st, slab, sp.splits, M, N, alpha, beta, C, ldc);
+                           st, slab, sp.splits, M, N, alpha, beta, C, ldc, bias);
         MGGCN_CHECK_LAUNCH();
     }
 }
+}  // namespace

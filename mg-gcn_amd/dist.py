@@ -463,9 +463,13 @@ class dist_row_linear:
     def __call__(self, dctx: dist_context, X: dist_row_dn_matrix, XW: dist_row_dn_matrix,
                  discard: bool = True) -> None:
         ctx, n = dctx.ctx, self.name
-        ops.broadcast_rows(ctx, self.b.local, XW.local, discard)
-        ctx.record(n + "0_0_matmul-gemm", 0)
-        ops.matmul(ctx, X.local, self.W.local, XW.local, 1.0, 1.0)
+        if self.fused and discard:
+            ctx.record(n + "0_0_matmul-gemm", 0)
+            ops.linear_forward(ctx, X.local, self.W.local, self.b.local, XW.local)
+        else:
+            ops.broadcast_rows(ctx, self.b.local, XW.local, discard)
+            ctx.record(n + "0_0_matmul-gemm", 0)
+            ops.matmul(ctx, X.local, self.W.local, XW.local, 1.0, 1.0)
         ctx.record(n + "0_1_matmul-gemm", 0)
         ctx.register_timer(n + "0_matmul-gemm", n + "0_0_matmul-gemm", n + "0_1_matmul-gemm")
         self.X = X

@@ -86,9 +86,13 @@ class linear:
 
     def __call__(self, ctx: context, X: dn_matrix, XW: dn_matrix, discard: bool = True) -> None:
         n = self.name
-        ops.broadcast_rows(ctx, self.b, XW, discard)
-        ctx.record(n + "0_0_matmul-gemm", 0)
-        ops.matmul(ctx, X, self.W, XW, 1.0, 1.0)
+        if self.fused and discard:                  # bias in the GEMM epilogue: one pass, C never read
+            ctx.record(n + "0_0_matmul-gemm", 0)
+            ops.linear_forward(ctx, X, self.W, self.b, XW)
+        else:
+            ops.broadcast_rows(ctx, self.b, XW, discard)
+            ctx.record(n + "0_0_matmul-gemm", 0)
+            ops.matmul(ctx, X, self.W, XW, 1.0, 1.0)
         ctx.record(n + "0_1_matmul-gemm", 0)
         ctx.register_timer(n + "0_matmul-gemm", n + "0_0_matmul-gemm", n + "0_1_matmul-gemm")
         self.X = X

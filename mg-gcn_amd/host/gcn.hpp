@@ -127,9 +127,14 @@ public:
     void setX(dn_t new_X) { X = new_X; }
 
     void operator()(context ctx, dn_t X, dn_t XW, bool discard = true) {
-        broadcast_rows(ctx, b, XW, discard);
-        ctx.record(name + "0_0_matmul-gemm", 0);
-        matmul(ctx, X, W, XW, (r_t)1, (r_t)1);
+        if (fused && discard) {                      // bias in the GEMM epilogue
+            ctx.record(name + "0_0_matmul-gemm", 0);
+            linear_forward(ctx, X, W, b, XW);
+        } else {
+            broadcast_rows(ctx, b, XW, discard);
+            ctx.record(name + "0_0_matmul-gemm", 0);
+            matmul(ctx, X, W, XW, (r_t)1, (r_t)1);
+        }
         ctx.record(name + "0_1_matmul-gemm", 0);
         ctx.register_timer(name + "0_matmul-gemm", name + "0_0_matmul-gemm", name + "0_1_matmul-gemm");
         this->X = X;
@@ -191,9 +196,14 @@ public:
     void setX(dn_t new_X) { X = new_X; }
 
     void operator()(dist_context ctx, dn_t X, dn_t XW, bool discard = true) {
-        broadcast_rows(ctx, b, XW, discard);
-        ctx.record(name + "0_0_matmul-gemm", 0);
-        matmul(ctx, X, W, XW, (r_t)1, (r_t)1);
+        if (fused && discard) {
+            ctx.record(name + "0_0_matmul-gemm", 0);
+            linear_forward(ctx, X, W, b, XW);
+        } else {
+            broadcast_rows(ctx, b, XW, discard);
+            ctx.record(name + "0_0_matmul-gemm", 0);
+            matmul(ctx, X, W, XW, (r_t)1, (r_t)1);
+        }
         ctx.record(name + "0_1_matmul-gemm", 0);
         ctx.register_timer(name + "0_matmul-gemm", name + "0_0_matmul-gemm", name + "0_1_matmul-gemm");
         this->X = X;

@@ -57,6 +57,18 @@ void matmul(const context ctx, const dn_matrix<r_t> A, const dn_matrix<r_t> B, c
                    B.buffer(), B.m(), beta, C.buffer(), C.m(), ctx.gemm_workspace(ws), ws);
 }
 
+// XW = X.W + 1 b^T with the bias in the GEMM epilogue (fused form of src/gcn.hpp:116-123)
+template <typename r_t>
+void linear_forward(const context ctx, const dn_matrix<r_t> X, const dn_matrix<r_t> W, const dn_matrix<r_t> b,
+                    const dn_matrix<r_t> XW) {
+    mggcn_require(X.m() == W.n() && XW.n() == X.n() && XW.m() == W.m() && b.m() == W.m() && b.n() == 1,
+                  "linear_forward: shape mismatch");
+    ctx.set();
+    const auto ws = mggcn_gemm_workspace_bytes(0, 0, (uint32_t)X.n(), (uint32_t)W.m(), (uint32_t)X.m());
+    mggcn_gemm_bias_f32(ctx.stream(0), 0, 0, (uint32_t)X.n(), (uint32_t)W.m(), (uint32_t)X.m(), (r_t)1, X.buffer(), X.m(),
+                        W.buffer(), W.m(), b.buffer(), XW.buffer(), XW.m(), ctx.gemm_workspace(ws), ws);
+}
+
 // ---- distributed SpMM: C_j = beta C_j + alpha sum_i A[j,i] B_i ------------------------------
 struct dist_spmm_buffers {
     std::vector<std::vector<spmm_buffer>> block;   // [j][i]  (rounds schedule)
@@ -152,6 +164,12 @@ template <typename r_t>
 void matmul(const dist_context ctx, const dist_row_dn_matrix<r_t> A, const repl_dn_matrix<r_t> B,
             const dist_row_dn_matrix<r_t> C, const r_t alpha, const r_t beta, const bool B_T = false) {
     for (std::size_t i = 0; i < ctx.size(); i++) matmul(ctx[i], A[i], B[i], C[i], alpha, beta, false, B_T);
+}
+
+template <typename r_t>
+void linear_forward(const dist_context ctx, const dist_row_dn_matrix<r_t> X, const repl_dn_matrix<r_t> W,
+                    const repl_dn_matrix<r_t> b, const dist_row_dn_matrix<r_t> XW) {
+    for (std::size_t i = 0; i < ctx.size(); i++) linear_forward(ctx[i], X[i], W[i], b[i], XW[i]);
 }
 
 // ---- BLAS-1 (reference src/cuda_utils.hpp:326-381) -------------------------------------------

@@ -85,6 +85,17 @@ def _gemm(ctx: context, A: dn_matrix, B: dn_matrix, C: dn_matrix, alpha: float, 
                            ws_bytes)
 
 
+def linear_forward(ctx: context, X: dn_matrix, W: dn_matrix, b: dn_matrix, XW: dn_matrix) -> None:
+    """XW = X.W + 1 b^T in one GEMM pass (bias in the epilogue) -- the fused form of the
+    reference's broadcast_rows + sgemm(beta = 1), src/gcn.hpp:116-123."""
+    _req(X.m() == W.n() and XW.n() == X.n() and XW.m() == W.m() and b.m() == W.m() and b.n() == 1, "linear shape")
+    ctx.set()
+    ws_bytes = ctx.lib.mggcn_gemm_workspace_bytes(0, 0, X.n(), W.m(), X.m())
+    ws = ctx.workspace(ws_bytes)
+    ctx.lib.mggcn_gemm_bias_f32(ctx.stream(0), 0, 0, X.n(), W.m(), X.m(), 1.0, X.buffer(), X.m(), W.buffer(), W.m(),
+                                b.buffer(), XW.buffer(), XW.m(), ws.data_ptr() if ws is not None else None, ws_bytes)
+
+
 # ---- element-wise / row kernels: src/cuda_utils.hpp:470-748 wrappers -----------------
 def leaky_relu_forward(ctx: context, in_: dn_matrix, out: dn_matrix, alpha: float = 0.01) -> None:
     _req(in_.shape() == out.shape(), "shape mismatch")

@@ -354,3 +354,23 @@ def test_sweep_equals_rowsplit_on_a_big_graph(pkg, ctx, monkeypatch):
     r, br = _run_spmm(pkg, ctx, A, B, z, 1.0, 0.0)
     assert br.num_sweep_tasks() == 0
     assert rowwise_relerr(s, r) <= 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 608), (777, 41, 128), (130, 48, 7), (5, 128, 9000)])
+def test_gemm_bias_epilogue_equals_broadcast_then_gemm(pkg, oracle, ctx, M, N, K):
+    """mggcn_gemm_bias_f32 = broadcast_rows + sgemm(beta = 1) of the reference's linear forward
+    (src/gcn.hpp:116-123): same sum, bit for bit, in one pass (tile path and split-K path)."""
+    rng = np.random.default_rng(M + N + K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, N)).astype(np.float32)
+    b = rng.standard_normal((1, N)).astype(np.float32)
+    Xd, Wd, bd = (pkg.dn_matrix.from_numpy(a) for a in (X, W, b))
+    fused = pkg.dn_matrix.from_numpy(np.full((M, N), np.nan, dtype=np.float32))      # C is never read
+    pkg.ops.linear_forward(ctx, Xd, Wd, bd, fused)
+    two = pkg.dn_matrix(M, N)
+    pkg.ops.broadcast_rows(ctx, bd, two, True)
+    pkg.matmul(ctx, Xd, Wd, two, 1.0, 1.0)
+    ctx.sync()
+    np.testing.assert_array_equal(fused.numpy(), two.numpy())
+    want = oracle.gemm(X, W, f64acc=True) + b
+    assert rowwise_relerr(fused.numpy(), want) <= TOL
