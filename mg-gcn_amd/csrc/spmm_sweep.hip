@@ -127,6 +127,53 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // index mode -- checked in the ISA.
 #define MGGCN_ROWS_GET(R) (VEC == 2 ? make_float2(p0[R], p1[R]) : make_float2(p0[R], 0.f))
 
+// ---- accumulator planes in RESERVED registers (float4 kernels) -------------------------------
+// The float4 kernels keep their 4 x 16 row accumulators in v[64:127], outside the register
+// allocator (the kernels are compiled with amdgpu_num_vgpr(64); the asm clobber lists make the
+// kernel's VGPR count 128 = four waves per SIMD, the residency the sweep wants anyway).  A run is
+// summed in compiler-managed registers (`acc`, packed FMAs, freely scheduled); at the run boundary
+// it is added to row `cur_row` of every plane with the index mode on the add itself:
+//     s_set_gpr_idx_on row, gpr_idx(SRC0,DST);  v_add_f32 v64, v64, acc.x;  ... x4 ;  s_set_gpr_idx_off
+// six instructions.  The compiler's own lowering of `p[cur_row] += acc` on a vector variable is
+// seven per plane (on / mov / off / add / on / mov / off): it cost 0.22 ms of the 2.9 ms d = 128
+// SpMM at 8192-row panels and 0.44 ms at 4096 (diag run with the fold skipped, r01).  (Indexing
+// the FMAs themselves -- no `acc`, no fold -- was slower: an on/off pair around every group of
+// four FMAs and no packed FMA, 2.97 ms.)
+#define MGGCN_PLANE_CLOBBERS "v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127"
+#define MGGCN_PLANES_ZERO() asm volatile("v_mov_b32 v64, 0\n\tv_mov_b32 v65, 0\n\tv_mov_b32 v66, 0\n\tv_mov_b32 v67, 0\n\tv_mov_b32 v68, 0\n\tv_mov_b32 v69, 0\n\tv_mov_b32 v70, 0\n\tv_mov_b32 v71, 0\n\tv_mov_b32 v72, 0\n\tv_mov_b32 v73, 0\n\tv_mov_b32 v74, 0\n\tv_mov_b32 v75, 0\n\tv_mov_b32 v76, 0\n\tv_mov_b32 v77, 0\n\tv_mov_b32 v78, 0\n\tv_mov_b32 v79, 0\n\tv_mov_b32 v80, 0\n\tv_mov_b32 v81, 0\n\tv_mov_b32 v82, 0\n\tv_mov_b32 v83, 0\n\tv_mov_b32 v84, 0\n\tv_mov_b32 v85, 0\n\tv_mov_b32 v86, 0\n\tv_mov_b32 v87, 0\n\tv_mov_b32 v88, 0\n\tv_mov_b32 v89, 0\n\tv_mov_b32 v90, 0\n\tv_mov_b32 v91, 0\n\tv_mov_b32 v92, 0\n\tv_mov_b32 v93, 0\n\tv_mov_b32 v94, 0\n\tv_mov_b32 v95, 0\n\tv_mov_b32 v96, 0\n\tv_mov_b32 v97, 0\n\tv_mov_b32 v98, 0\n\tv_mov_b32 v99, 0\n\tv_mov_b32 v100, 0\n\tv_mov_b32 v101, 0\n\tv_mov_b32 v102, 0\n\tv_mov_b32 v103, 0\n\tv_mov_b32 v104, 0\n\tv_mov_b32 v105, 0\n\tv_mov_b32 v106, 0\n\tv_mov_b32 v107, 0\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v109, 0\n\tv_mov_b32 v110, 0\n\tv_mov_b32 v111, 0\n\tv_mov_b32 v112, 0\n\tv_mov_b32 v113, 0\n\tv_mov_b32 v114, 0\n\tv_mov_b32 v115, 0\n\tv_mov_b32 v116, 0\n\tv_mov_b32 v117, 0\n\tv_mov_b32 v118, 0\n\tv_mov_b32 v119, 0\n\tv_mov_b32 v120, 0\n\tv_mov_b32 v121, 0\n\tv_mov_b32 v122, 0\n\tv_mov_b32 v123, 0\n\tv_mov_b32 v124, 0\n\tv_mov_b32 v125, 0\n\tv_mov_b32 v126, 0\n\tv_mov_b32 v127, 0" ::: MGGCN_PLANE_CLOBBERS)
+#define MGGCN_PLANES_FOLD(ROW, ACC)                                                             \
+    asm volatile("s_set_gpr_idx_on %0, gpr_idx(SRC0,DST)\n\t"                                   \
+                 "v_add_f32 v64, v64, %1\n\t"                                                   \
+                 "v_add_f32 v80, v80, %2\n\t"                                                   \
+                 "v_add_f32 v96, v96, %3\n\t"                                                   \
+                 "v_add_f32 v112, v112, %4\n\t"                                                 \
+                 "s_set_gpr_idx_off"                                                             \
+                 :: "s"(ROW), "v"((ACC)[0]), "v"((ACC)[1]), "v"((ACC)[2]), "v"((ACC)[3])         \
+                 : MGGCN_PLANE_CLOBBERS)
+#define MGGCN_PLANES_GET(X0, X1, X2, X3, R0, R1, R2, R3)                                        \
+    asm volatile("v_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 "\n\tv_mov_b32 %2, " R2 "\n\tv_mov_b32 %3, " R3 \
+                 : "=v"(X0), "=v"(X1), "=v"(X2), "=v"(X3) :: MGGCN_PLANE_CLOBBERS)
+#define MGGCN_PLANES_EMIT_ONE(EMIT, R, R0, R1, R2, R3)                                          \
+    { float x0_, x1_, x2_, x3_; MGGCN_PLANES_GET(x0_, x1_, x2_, x3_, R0, R1, R2, R3); EMIT(R, x0_, x1_, x2_, x3_); }
+// EMIT(R, x0, x1, x2, x3) for R = 0..15, the plane registers spelled out
+#define MGGCN_PLANES_EMIT_ALL(EMIT) \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 0, "v64", "v80", "v96", "v112") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 1, "v65", "v81", "v97", "v113") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 2, "v66", "v82", "v98", "v114") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 3, "v67", "v83", "v99", "v115") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 4, "v68", "v84", "v100", "v116") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 5, "v69", "v85", "v101", "v117") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 6, "v70", "v86", "v102", "v118") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 7, "v71", "v87", "v103", "v119") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 8, "v72", "v88", "v104", "v120") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 9, "v73", "v89", "v105", "v121") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 10, "v74", "v90", "v106", "v122") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 11, "v75", "v91", "v107", "v123") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 12, "v76", "v92", "v108", "v124") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 13, "v77", "v93", "v109", "v125") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 14, "v78", "v94", "v110", "v126") \
+    MGGCN_PLANES_EMIT_ONE(EMIT, 15, "v79", "v95", "v111", "v127")
+
 template <int VEC> __device__ __forceinline__ Vec<VEC> vec_from2(float2 x);
 template <> __device__ __forceinline__ Vec<1> vec_from2<1>(float2 x) { Vec<1> r; r.v = x.x; return r; }
 template <> __device__ __forceinline__ Vec<2> vec_from2<2>(float2 x) { Vec<2> r; r.v = x; return r; }
@@ -264,7 +311,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_kernel(
 // sums of the SAME output row (the run's row is still wave-uniform -> index-mode fold); the
 // halves are added once per task at write-out.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr(64))) void spmm_sweep_pair_kernel(
     const SweepTask *__restrict__ tasks, uint32_t task0, uint32_t n_launch,
     const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
     const float *__restrict__ B, uint32_t b_bytes, uint32_t row_bytes, float *__restrict__ C, size_t ldc,
@@ -284,9 +331,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair_kernel(
         const uint32_t col = col0 + sub * 4;
         const bool active = col < d;
         const uint32_t lane_off = (active ? col : 0) * 4u;
-        f32x16 p0, p1, p2, p3;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { p0[r] = 0.f; p1[r] = 0.f; p2[r] = 0.f; p3[r] = 0.f; }
+        MGGCN_PLANES_ZERO();
         uint32_t cur_row = 0;
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 
@@ -307,10 +352,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair_kernel(
                 for (int u = 0; u < 4; u++) {
                     const uint32_t pk = cur.pk(2 * u);
                     if (pk & kRunFlag) {                                   // first pair of a (panel,row) run
-                        p0[cur_row] += acc[0];
-                        p1[cur_row] += acc[1];
-                        p2[cur_row] += acc[2];
-                        p3[cur_row] += acc[3];
+                        MGGCN_PLANES_FOLD(cur_row, acc);
                         acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                         cur_row = (pk >> kColBits) & (kRW - 1);
                     }
@@ -325,10 +367,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair_kernel(
                 cur = nxt;
             }
         }
-        p0[cur_row] += acc[0];
-        p1[cur_row] += acc[1];
-        p2[cur_row] += acc[2];
-        p3[cur_row] += acc[3];
+        MGGCN_PLANES_FOLD(cur_row, acc);
 
         // add the two half-waves' partial rows, then the common epilogue from lanes 0..31
         auto emit = [&](uint32_t r, float x0, float x1, float x2, float x3) {
@@ -353,10 +392,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_pair_kernel(
             }
             *cp = s;
         };
-#define MGGCN_EMIT(R) emit(R, p0[R], p1[R], p2[R], p3[R]);
-        MGGCN_EMIT(0) MGGCN_EMIT(1) MGGCN_EMIT(2) MGGCN_EMIT(3) MGGCN_EMIT(4) MGGCN_EMIT(5) MGGCN_EMIT(6) MGGCN_EMIT(7)
-        MGGCN_EMIT(8) MGGCN_EMIT(9) MGGCN_EMIT(10) MGGCN_EMIT(11) MGGCN_EMIT(12) MGGCN_EMIT(13) MGGCN_EMIT(14) MGGCN_EMIT(15)
-#undef MGGCN_EMIT
+        MGGCN_PLANES_EMIT_ALL(emit)
     }
 }
 
@@ -398,7 +434,7 @@ __global__ __launch_bounds__(256) void sweep_repack_kernel(const float *__restri
 // ds_read_b64: no select, no scalar multiply; the run flag / row of the quad's first entry comes
 // from lane 0 (v_readfirstlane).  ~5 vector ops per quad -> the kernel is left with the gather
 // instructions themselves.
-__global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_quad_lds_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr(64))) void spmm_sweep_quad_lds_kernel(
     const SweepTask *__restrict__ tasks, uint32_t task0, uint32_t n_launch,
     const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
     const float *__restrict__ B, uint32_t b_bytes, uint32_t row_bytes, float *__restrict__ C, size_t ldc,
@@ -416,9 +452,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_quad_lds_kerne
     const uint32_t col = sub * 4;
     const bool active = col < d;
     const uint32_t lane_off = (active ? col : 0) * 4u;
-    f32x16 p0, p1, p2, p3;
-#pragma unroll
-    for (int r = 0; r < 16; r++) { p0[r] = 0.f; p1[r] = 0.f; p2[r] = 0.f; p3[r] = 0.f; }
+    MGGCN_PLANES_ZERO();
     uint32_t cur_row = 0;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 
@@ -450,10 +484,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_quad_lds_kerne
                 for (int u = 0; u < 4; u++) {
                     const uint32_t pk = __builtin_amdgcn_readfirstlane(ent[u].x);
                     if (pk & kRunFlag) {                                   // first quad of a (panel,row) run
-                        p0[cur_row] += acc[0];
-                        p1[cur_row] += acc[1];
-                        p2[cur_row] += acc[2];
-                        p3[cur_row] += acc[3];
+                        MGGCN_PLANES_FOLD(cur_row, acc);
                         acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                         cur_row = (pk >> kColBits) & (kRW - 1);
                     }
@@ -467,10 +498,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_quad_lds_kerne
             __builtin_amdgcn_wave_barrier();
         }
     }
-    p0[cur_row] += acc[0];
-    p1[cur_row] += acc[1];
-    p2[cur_row] += acc[2];
-    p3[cur_row] += acc[3];
+    MGGCN_PLANES_FOLD(cur_row, acc);
 
     auto emit = [&](uint32_t r, float x0, float x1, float x2, float x3) {
         if (r >= task.n_rows) return;                                    // wave-uniform
@@ -496,10 +524,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_quad_lds_kerne
             cp[k] = o;
         }
     };
-#define MGGCN_EMIT(R) emit(R, p0[R], p1[R], p2[R], p3[R]);
-    MGGCN_EMIT(0) MGGCN_EMIT(1) MGGCN_EMIT(2) MGGCN_EMIT(3) MGGCN_EMIT(4) MGGCN_EMIT(5) MGGCN_EMIT(6) MGGCN_EMIT(7)
-    MGGCN_EMIT(8) MGGCN_EMIT(9) MGGCN_EMIT(10) MGGCN_EMIT(11) MGGCN_EMIT(12) MGGCN_EMIT(13) MGGCN_EMIT(14) MGGCN_EMIT(15)
-#undef MGGCN_EMIT
+    MGGCN_PLANES_EMIT_ALL(emit)
 }
 
 __global__ __launch_bounds__(256) void sweep_combine_kernel(
@@ -535,7 +560,7 @@ struct VRow {
 
 uint32_t sweep_panel_rows(uint32_t d_hint) {
     if (d_hint >= 1 && d_hint <= 64) return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS_NARROW", 16384u));
-    return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 8192u));
+    return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 6144u));
 }
 
 struct SweepPlan {
@@ -570,7 +595,10 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     // column space is what decides the L2 hit rate.  Measured on the Reddit shape, d = 128
     // (profiles/experiments/sweep_vs_rowsplit.py): 2 blocks/CU 3.96 ms, 3 -> 3.34 ms, 4 -> 4.0,
     // 5 -> 4.0, 6 -> 4.4 (row-split kernel: 5.96 ms).  With the float4 pair kernel and 32 MiB
-    // column slices (spmm.hip) the optimum moved to 4 blocks/CU, 8192-row panels: 2.83 ms.
+    // column slices (spmm.hip) the optimum moved to 4 blocks/CU, 8192-row panels: 2.83 ms; with
+    // the accumulators in reserved registers and the six-instruction fold, 6144-row panels and
+    // 64 MiB slices: 2.69 ms (3 blocks/CU 3.11, 5 -> 3.56; the float4 kernels hold 128 VGPRs, so
+    // four blocks of four waves is also what fits).
     const uint32_t blocks_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u), 8u));
     const uint32_t round_tasks = kNumCU * blocks_per_cu * kWavesPerBlock;
 

@@ -194,3 +194,44 @@ def test_prepare_dataset_pads_loops_and_permutes(pkg, tmp_path):
     perm = np.random.default_rng(3).permutation(n)
     np.testing.assert_array_equal(dense2, dense[perm][:, perm])
     np.testing.assert_array_equal(X3, X2[perm])
+
+
+def test_reserved_accumulator_registers_are_left_alone_by_the_compiler(tmp_path):
+    """The float4 sweep kernels keep their accumulator planes in v[64:127] behind the register
+    allocator's back (amdgpu_num_vgpr(64) + asm clobbers, csrc/spmm_sweep.hip).  Guard the
+    contract at build time: in those kernels no compiler-generated instruction may name a VGPR
+    >= 64, the kernels must be allotted 128 VGPRs, and nothing may spill to scratch."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "mg-gcn_amd", "csrc", "spmm_sweep.hip")
+    out = tmp_path / "sweep.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                        "-S", "--cuda-device-only", src, "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    hi = re.compile(r"\bv(6[4-9]|[7-9][0-9]|[12][0-9][0-9])\b|v\[(6[4-9]|[7-9][0-9]|[12][0-9][0-9]):")
+    kern, inside, seen = None, False, set()
+    for line in text.split("\n"):
+        m = re.match(r"^(_Z\S*):", line)
+        if m:
+            kern = m.group(1)
+        if "ASMSTART" in line:
+            inside = True
+            continue
+        if "ASMEND" in line:
+            inside = False
+            continue
+        if kern and ("spmm_sweep_pair_kernel" in kern or "spmm_sweep_quad_lds_kernel" in kern):
+            seen.add("pair" if "pair" in kern else "quad")
+            st = line.strip()
+            if not inside and st and not st.startswith((".", ";")) and hi.search(st):
+                raise AssertionError(f"{kern}: compiler-generated instruction touches a reserved register: {st}")
+    assert seen == {"pair", "quad"}
+    for name in ("spmm_sweep_pair_kernel", "spmm_sweep_quad_lds_kernel"):
+        meta = text[text.index(".name:", text.index("amdhsa.kernels")):]
+        blk = meta[meta.index(name):]
+        blk = blk[:blk.index(".wavefront_size")] if ".wavefront_size" in blk else blk[:2000]
+        assert re.search(r"\.vgpr_count:\s+128\b", blk), (name, blk[:400])
+        assert re.search(r"\.private_segment_fixed_size:\s+0\b", blk), (name, blk[:400])
