@@ -261,7 +261,7 @@ struct mggcn_spmm_plan {
     // column-panel sweep form (large matrices; spmm_sweep.hip): one plan per column SLICE of
     // the matrix, run back to back with beta accumulation (see mggcn_spmm_plan_create)
     std::vector<SweepPlan *> sweeps;
-    // narrow form (d_hint <= 64): scratch for B re-pitched to 16-byte rows, n_cols x bpad_dp floats
+    // narrow form (d_hint <= 64): scratch for B re-pitched to 64-byte-multiple rows, n_cols x bpad_dp floats
     float *d_bpad = nullptr;
     uint32_t bpad_dp = 0;
 };
@@ -394,7 +394,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
             }
         }
         if (narrow && !plan->sweeps.empty()) {
-            plan->bpad_dp = (d_hint + 3) / 4 * 4;
+            plan->bpad_dp = (d_hint + 15) / 16 * 16;       // 64-byte pitch: see sweep_wants_repack
             const size_t bb = (size_t)n_cols * plan->bpad_dp * sizeof(float);
             MGGCN_CHECK_HIP(hipMalloc(&plan->d_bpad, bb));
             plan->bytes += bb;
@@ -475,9 +475,9 @@ MGGCN_API void mggcn_spmm_csr_f32(mggcn_stream_t stream, const mggcn_spmm_plan *
         MGGCN_REQUIRE(d <= plan->max_d || plan->n_slots == 0, "feature width exceeds the plan's max_d");
         if (!plan->sweeps.empty() && sweep_supports(plan->sweeps[0], d, ldb, ldc, B, C)) {
             const size_t S = plan->sweeps.size();
-            const uint32_t dp = (d + 3) / 4 * 4;
+            const uint32_t dp = (d + 15) / 16 * 16;
             if (plan->d_bpad && dp <= plan->bpad_dp && sweep_wants_repack(plan->sweeps[0], d, ldb, B)) {
-                sweep_repack(st, B, ldb, n_cols, d, plan->d_bpad, dp);     // 16-byte pitched copy of B
+                sweep_repack(st, B, ldb, n_cols, d, plan->d_bpad, dp);     // 64-byte pitched copy of B
                 B = plan->d_bpad;
                 ldb = dp;
             }

@@ -14,6 +14,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
                             uint32_t d_hint = 0);
 // d_hint in 1..64 builds the narrow ("quad") form: runs padded to four entries, wider panels
 uint32_t sweep_panel_rows(uint32_t d_hint);
+uint32_t sweep_lanes_per_entry(uint32_t d_hint);   // 4 / 8 / 12 / 16 float4 lanes per gathered row
 // narrow form only: true when B has to be re-pitched to 16-byte rows before sweep_launch
 bool sweep_wants_repack(const SweepPlan *p, uint32_t d, size_t ldb, const void *B);
 void sweep_repack(hipStream_t st, const float *B, size_t ldb, uint32_t n_cols, uint32_t d, float *out, uint32_t dp);

@@ -26,6 +26,7 @@
 // XCD and then hit in L2 by ~600 waves.  Placement is a speed matter only; results
 // never depend on it.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <queue>
 #include <thread>
@@ -397,18 +398,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
 }
 
 // ---------------------------------------------------------------------------------------
-// float4 "quad" form for narrow rows (d <= 64; the reference's logits layer has d = 41).
-// Measured cost of one row-gather wave-instruction on this chip, in cycles per CU, everything
-// hitting L1/L2 (profiles/experiments/narrow_spmm.py, l2_window.py): dword 11, dwordx2 18,
-// dwordx4 22-26 -- nearly independent of how many lanes are live or how many bytes come back.
-// The one-column-per-lane kernel spends a whole instruction on one 164-byte row (2.12 ms on the
-// Reddit shape, with or without L2 locality).  Here B is first re-pitched to a multiple of 4
-// floats (sweep_repack_kernel: 16-byte aligned rows, one streaming pass of n_cols x d floats), a
-// row is 16 lanes x float4 and ONE buffer_load_dwordx4 fetches the rows of FOUR entries, one per
-// quarter-wave (the plan pads every run to a multiple of four): 6.5 cycles per entry instead of
-// 11.  All four quarters accumulate the SAME output row (wave-uniform -> index-mode fold); they
-// are added once per task.  1.85 ms.  (Tried and dropped: 8-byte lanes at 4-byte alignment, two
-// rows per instruction -- no faster than one row per instruction.)
+// float4 narrow-row form (d <= 64; the reference's logits layer has d = 41, 48 at P = 8).
+// Measured on this chip, everything hitting L1/L2 (profiles/experiments/narrow_spmm.py,
+// l2_window.py): a row-gather wave-instruction is priced by the 128-byte LINES it touches, about
+// 2.7 cycles per line per CU (vector-L1 tag/data rate) on top of ~8-11 for the instruction itself:
+// dword x 41 lanes (one 164-byte row, 2-3 lines) 11 cycles, dwordx4 over two 512-byte rows (8 lines)
+// 22, over four 176-byte rows 26, over sixteen 64-byte rows 62.  The one-column-per-lane kernel
+// spends a whole instruction on one 164-byte row (2.12 ms on the Reddit shape, with or without L2
+// locality).  Here B is first re-pitched to a multiple of 64 bytes (sweep_repack_kernel: one
+// streaming pass of n_cols x d floats; a 164/176-byte pitch puts 37 % of the rows on three lines,
+// a 192-byte pitch never more than two), a row is LPE lanes x float4 and ONE buffer_load_dwordx4
+// fetches the rows of G = 64 / LPE entries (the plan pads every run to a multiple of G; d = 41:
+// LPE = 12, five rows per instruction).  All groups accumulate the SAME output row (wave-uniform
+// -> index-mode fold); they are added once per task.  1.63 ms.  (Tried and dropped: 8-byte lanes
+// at 4-byte alignment, two rows per instruction -- no faster than one row per instruction.)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sweep_repack_kernel(const float *__restrict__ B, size_t ldb, uint32_t n,
                                                            uint32_t d, float *__restrict__ out, uint32_t dp) {
@@ -434,6 +437,23 @@ __global__ __launch_bounds__(256) void sweep_repack_kernel(const float *__restri
 // ds_read_b64: no select, no scalar multiply; the run flag / row of the quad's first entry comes
 // from lane 0 (v_readfirstlane).  ~5 vector ops per quad -> the kernel is left with the gather
 // instructions themselves.
+// LPE = lanes per entry (16 B each): 16 -> rows up to 64 floats, 4 entries per instruction;
+// 12 -> up to 48 floats, 5 entries (the logits layer: 41 classes, 48 at P = 8); 8 -> 32 floats, 8
+// entries; 4 -> 16 floats, 16 entries.  The plan pads runs to G = 64 / LPE entries.
+template <int LPE> __device__ __forceinline__ float reduce_groups(float x) {
+    if constexpr (LPE == 12) {                      // 5 groups at lanes 0,12,24,36,48
+        const float far = __shfl_down(x, 48);       // group 4 -> lanes 0..11
+        x += __shfl_down(x, 24);                    // groups 2,3 -> 0,1
+        x += __shfl_down(x, 12);                    // group 1 -> 0
+        return x + far;
+    } else {
+#pragma unroll
+        for (int o = LPE; o < 64; o <<= 1) x += __shfl_xor(x, o);
+        return x;
+    }
+}
+
+template <int LPE>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr(64))) void spmm_sweep_quad_lds_kernel(
     const SweepTask *__restrict__ tasks, uint32_t task0, uint32_t n_launch,
     const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
@@ -448,31 +468,37 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
     const SweepTask task = tasks[t];
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, b_bytes, 0x00020000);
-    const uint32_t sub = lane & 15, quarter = lane >> 4;
+    constexpr int G = 64 / LPE;                       // entries per gather instruction
+    constexpr int STEP = 4 * G;                       // entries per loop step (four gathers in flight)
+    constexpr int CH = (128 / STEP) * STEP;           // entries consumed per 1 KiB LDS chunk
+    const uint32_t sub = lane % LPE;
+    const bool live = lane < G * LPE;                 // LPE = 12 leaves lanes 60..63 idle
+    const uint32_t grp = live ? lane / LPE : G - 1;
     const uint32_t col = sub * 4;
-    const bool active = col < d;
+    const bool active = live && col < d;
     const uint32_t lane_off = (active ? col : 0) * 4u;
     MGGCN_PLANES_ZERO();
     uint32_t cur_row = 0;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 
-    const uint32_t n_ent = task.end - task.beg;           // multiple of 16
+    const uint32_t n_ent = task.end - task.beg;           // multiple of STEP
     if (n_ent) {
+        // every chunk is loaded as 128 entries (1 KiB) starting at entry c * CH; CH of them are used
         const uint4 *stream = reinterpret_cast<const uint4 *>(entries + task.beg) + lane;   // 2 entries per uint4
-        const uint32_t n_chunks = (n_ent + 127) / 128;    // the plan leaves a chunk of slack after the last task
+        const uint32_t n_chunks = (n_ent + CH - 1) / CH;  // the plan leaves a chunk of slack after the last task
         ring[wib][0][lane] = stream[0];
-        uint4 pre = stream[n_chunks > 1 ? 64 : 0];
+        uint4 pre = stream[n_chunks > 1 ? CH / 2 : 0];
         for (uint32_t c = 0; c < n_chunks; c++) {
             ring[wib][(c + 1) & 1][lane] = pre;           // chunk c+1 (slot last read during chunk c-1)
-            pre = stream[(size_t)64 * (c + 2 < n_chunks ? c + 2 : c)];
+            pre = stream[(size_t)(CH / 2) * (c + 2 < n_chunks ? c + 2 : c)];
             __builtin_amdgcn_wave_barrier();
-            const uint2 *slot = reinterpret_cast<const uint2 *>(&ring[wib][c & 1][0]) + quarter;
-            const uint32_t n_steps = min(8u, (n_ent - c * 128) / 16);
+            const uint2 *slot = reinterpret_cast<const uint2 *>(&ring[wib][c & 1][0]) + grp;
+            const uint32_t n_steps = min((uint32_t)(CH / STEP), (n_ent - c * CH) / STEP);
             for (uint32_t s = 0; s < n_steps; s++) {
                 uint2 ent[4];
                 f32x4_t b[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) ent[u] = slot[s * 16 + u * 4];
+                for (int u = 0; u < 4; u++) ent[u] = slot[s * STEP + u * G];
 #pragma unroll
                 for (int u = 0; u < 4; u++) b[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                 if (active) {                                    // lanes past the row issue no load (3 % faster)
@@ -483,7 +509,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const uint32_t pk = __builtin_amdgcn_readfirstlane(ent[u].x);
-                    if (pk & kRunFlag) {                                   // first quad of a (panel,row) run
+                    if (pk & kRunFlag) {                                   // first group of a (panel,row) run
                         MGGCN_PLANES_FOLD(cur_row, acc);
                         acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                         cur_row = (pk >> kColBits) & (kRW - 1);
@@ -502,9 +528,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
 
     auto emit = [&](uint32_t r, float x0, float x1, float x2, float x3) {
         if (r >= task.n_rows) return;                                    // wave-uniform
-        x0 += __shfl_xor(x0, 16); x1 += __shfl_xor(x1, 16); x2 += __shfl_xor(x2, 16); x3 += __shfl_xor(x3, 16);
-        x0 += __shfl_xor(x0, 32); x1 += __shfl_xor(x1, 32); x2 += __shfl_xor(x2, 32); x3 += __shfl_xor(x3, 32);
-        if (!active || quarter) return;
+        x0 = reduce_groups<LPE>(x0); x1 = reduce_groups<LPE>(x1);
+        x2 = reduce_groups<LPE>(x2); x3 = reduce_groups<LPE>(x3);
+        if (!active || grp) return;
         const uint32_t dst = task_rows[(size_t)t * kRW + r];
         const float xs[4] = {x0, x1, x2, x3};
         if (dst & kSlotFlag) {
@@ -558,15 +584,27 @@ struct VRow {
 
 }  // namespace
 
+uint32_t sweep_lanes_per_entry(uint32_t d_hint) {
+    const uint32_t need = (d_hint + 3) / 4;          // float4 lanes that cover a row
+    return need <= 4 ? 4u : need <= 8 ? 8u : need <= 12 ? 12u : 16u;
+}
+
 uint32_t sweep_panel_rows(uint32_t d_hint) {
-    if (d_hint >= 1 && d_hint <= 64) return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS_NARROW", 16384u));
+    if (d_hint >= 1 && d_hint <= 64) {
+        // 1.5 MiB of B per panel at the 64-byte-multiple pitch: 8192 rows at d = 41 (best of 8192 /
+        // 16384 / 32768 on both Reddit matrices), 24576 at d = 16 (16384 beat 8192 there)
+        const uint32_t pitch = (d_hint + 15) / 16 * 64;
+        const uint32_t rows = std::max(1024u, (3u << 19) / pitch / 1024u * 1024u);
+        return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS_NARROW", rows));
+    }
     return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 6144u));
 }
 
 struct SweepPlan {
     uint32_t n_rows = 0, n_cols = 0, max_d = 0;
     uint32_t n_tasks = 0, round_tasks = 0, n_split_rows = 0, n_slots = 0;
-    uint32_t run_pad = 2;          // every (panel,row) run is a multiple of this many entries (4: quad form)
+    uint32_t run_pad = 2;          // every (panel,row) run is a multiple of this many entries
+    uint32_t lpe = 0;              // narrow form: lanes per entry of the gather kernel (run_pad = 64 / lpe); 0 = wide form
     SweepTask *d_tasks = nullptr;
     uint2 *d_entries = nullptr;
     uint32_t *d_task_rows = nullptr;
@@ -582,7 +620,11 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     // narrow form (quad kernel): runs padded to 4 entries, tasks to 16, wider panels (the L2
     // window is counted in bytes: a 176-byte row lets three times as many rows stay resident)
     const bool narrow = d_hint >= 1 && d_hint <= 64 && n_cols <= (1u << 24);
-    const uint32_t G = narrow ? 4u : 2u, batch_pad = narrow ? 16u : 8u;
+    // lanes per gathered row / entries per gather instruction: the fewest lanes that cover the row
+    // give the most rows per instruction, but every run is padded to G entries -- on a matrix with
+    // many short runs (power-law rows) a smaller G wins.  Decided after the counting pass below.
+    uint32_t lpe = !narrow ? 0u : sweep_lanes_per_entry(d_hint);
+    uint32_t G = narrow ? 64u / lpe : 2u;
     if (n_cols > kColMask) return nullptr;                          // column does not fit the packed entry
     static_assert(kRW == 16, "4 row bits in the packed entry");
     const uint64_t nnz = (uint64_t)indptr[n_rows] - indptr[0];
@@ -678,16 +720,53 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
             }
         }
     };
-    std::vector<uint64_t> plen(T, 0);
+    // candidate forms: this lpe and every wider one (4 -> 16 entries per instruction, 8 -> 8, 12 -> 5, 16 -> 4)
+    static const uint32_t kLpes[4] = {4u, 8u, 12u, 16u};
+    std::vector<uint32_t> cand;
+    if (narrow) {
+        const uint32_t forced = env_u32("MGGCN_SPMM_NARROW_LPE", 0u);
+        for (uint32_t l : kLpes)
+            if (l >= lpe && (!forced || l == forced)) cand.push_back(l);
+        if (cand.empty()) cand.push_back(lpe);
+    }
+    const size_t NC = narrow ? cand.size() : 1;
+    std::vector<uint64_t> plen_c((size_t)T * NC, 0);
     run_parallel([&](unsigned tid) {
         std::vector<uint32_t> cnt(n_buckets);
         for (uint32_t t = tid; t < T; t += NT) {
             count_buckets(t, cnt);
-            uint64_t len = 0;
-            for (uint32_t c : cnt) len += (c + G - 1) / G * G;
-            plen[t] = len;
+            for (size_t k = 0; k < NC; k++) {
+                const uint32_t g = narrow ? 64u / cand[k] : G;
+                uint64_t len = 0;
+                for (uint32_t c : cnt) len += (c + g - 1) / g * g;
+                plen_c[(size_t)t * NC + k] = len;
+            }
         }
     });
+    size_t pick = 0;
+    if (narrow) {
+        // cost of one gather instruction ~ 3 + 2.7 cycles per 128-byte line touched (fitted:
+        // profiles/experiments/narrow_backward.py -- at d = 41 five rows per instruction are no faster
+        // than four on the even-row forward matrix, 13 % slower on the power-law backward one; at
+        // d = 16 sixteen rows per instruction are 1.5x faster than four); rows are pitched to a
+        // multiple of 64 bytes
+        const double lines = std::max(1.0, std::ceil(((d_hint + 15) / 16 * 64) / 128.0));
+        double best = 0;
+        for (size_t k = 0; k < NC; k++) {
+            const uint32_t g = 64u / cand[k];
+            uint64_t tot = 0;
+            for (uint32_t t = 0; t < T; t++) tot += plen_c[(size_t)t * NC + k];
+            const double cost = (double)tot * (3.0 + 2.7 * lines * g) / g;
+            if (k == 0 || cost < best) { best = cost; pick = k; }
+        }
+        lpe = cand[pick];
+        G = 64u / lpe;
+    }
+    // task streams are whole steps of the narrow kernel (4 G entries) AND whole 8-entry batches of the others
+    const uint32_t batch_pad = !narrow ? 8u : (G == 5u ? 40u : std::max(4u * G, 8u));
+    std::vector<uint64_t> plen(T, 0);
+    for (uint32_t t = 0; t < T; t++) plen[t] = plen_c[(size_t)t * NC + pick];
+    std::vector<uint64_t>().swap(plen_c);
     std::vector<SweepTask> tasks(T);
     std::vector<uint32_t> task_rows((size_t)T * kRW, 0u);
     uint64_t off = 0;
@@ -724,8 +803,9 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
                 if (!cnt[k]) continue;
                 const uint32_t s0 = start[k], s1 = start[k + 1];
                 for (uint32_t q = s0 + cnt[k]; q < s1; q++) out[q] = make_uint2(out[s0 + cnt[k] - 1].x, 0u);   // pad the run
-                for (uint32_t q = s0; q < s1; q += 2)                                // pair: lower column first
-                    if ((out[q].x & kColMask) > (out[q + 1].x & kColMask)) std::swap(out[q], out[q + 1]);
+                if (G % 2 == 0)
+                    for (uint32_t q = s0; q < s1; q += 2)                            // pair: lower column first
+                        if ((out[q].x & kColMask) > (out[q + 1].x & kColMask)) std::swap(out[q], out[q + 1]);
                 out[s0].x |= kRunFlag;                                               // first entry of the run
             }
             // tail padding up to the 8-entry batch: zero-valued copies of the last entry, no run flag
@@ -736,7 +816,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
 
     auto *p = new SweepPlan;
     p->n_rows = n_rows; p->n_cols = n_cols; p->max_d = max_d;
-    p->n_tasks = T; p->round_tasks = round_tasks; p->run_pad = G;
+    p->n_tasks = T; p->round_tasks = round_tasks; p->run_pad = G; p->lpe = lpe;
     p->n_split_rows = (uint32_t)split_rows.size(); p->n_slots = n_slots;
     const size_t tb = tasks.size() * sizeof(SweepTask), eb = entries.size() * sizeof(uint2);
     const size_t rb = task_rows.size() * sizeof(uint32_t), sb = split_rows.size() * sizeof(SweepSplitRow);
@@ -781,8 +861,11 @@ bool sweep_supports(const SweepPlan *p, uint32_t d, size_t ldb, size_t ldc, cons
 }
 
 bool sweep_wants_repack(const SweepPlan *p, uint32_t d, size_t ldb, const void *B) {
-    if (!p || p->run_pad != 4 || d > 64 || env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) == 0) return false;
-    return !(ldb % 4 == 0 && aligned16(B));
+    if (!p || !p->lpe || d > 4 * p->lpe || env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) == 0) return false;
+    // The gather path is priced per 128-byte line touched (~2.7 cycles each, narrow_spmm.py: 16 rows of
+    // 64 B per instruction cost 62 cycles, 4 rows of 176 B 26): a 176-byte pitch puts 37 % of the rows
+    // on three lines, a pitch that is a multiple of 64 B never more than two.
+    return !(ldb % 16 == 0 && (reinterpret_cast<uintptr_t>(B) & 63u) == 0);
 }
 
 void sweep_repack(hipStream_t st, const float *B, size_t ldb, uint32_t n_cols, uint32_t d, float *out, uint32_t dp) {
@@ -796,11 +879,11 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
                   uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
     // narrow rows on a quad-padded stream: B must be 16-byte pitched (the caller re-pitches it
     // with sweep_repack when sweep_wants_repack says so)
-    const bool quad = p->run_pad == 4 && d <= 64 && ldb % 4 == 0 && aligned16(B) &&
+    const bool quad = p->lpe && d <= 4 * p->lpe && ldb % 4 == 0 && aligned16(B) &&
                       env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) != 0;
     // float4 pair form: 16-byte aligned rows of >= 96 columns (narrower rows would idle most of
     // a half-wave); float2 lanes need 8-byte aligned rows; otherwise one column per lane
-    const bool vec4 = d >= 96 && d % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C) &&
+    const bool vec4 = p->run_pad % 2 == 0 && d >= 96 && d % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C) &&
                       env_u32("MGGCN_SPMM_SWEEP_VEC4", 1u) != 0;
     const bool vec2 = d > 64 && d % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 &&
                       (reinterpret_cast<uintptr_t>(B) & 7u) == 0 && (reinterpret_cast<uintptr_t>(C) & 7u) == 0;
@@ -812,10 +895,16 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
     for (uint32_t t0 = 0; t0 < p->n_tasks; t0 += per_launch) {
         const uint32_t n_launch = std::min(per_launch, p->n_tasks - t0);
         const dim3 grid((n_launch + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
-        if (quad)
-            hipLaunchKernelGGL(spmm_sweep_quad_lds_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
-                               p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
-                               alpha, beta, flags, slope);
+#define MGGCN_LAUNCH_NARROW(L)                                                                             \
+    hipLaunchKernelGGL((spmm_sweep_quad_lds_kernel<L>), grid, block, 0, st, p->d_tasks, t0, n_launch, p->d_entries, \
+                       p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d, alpha, beta, flags, slope)
+        if (quad) {
+            if (p->lpe == 4) MGGCN_LAUNCH_NARROW(4);
+            else if (p->lpe == 8) MGGCN_LAUNCH_NARROW(8);
+            else if (p->lpe == 12) MGGCN_LAUNCH_NARROW(12);
+            else MGGCN_LAUNCH_NARROW(16);
+        }
+#undef MGGCN_LAUNCH_NARROW
         else if (vec4)
             hipLaunchKernelGGL(spmm_sweep_pair_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,

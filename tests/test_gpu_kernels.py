@@ -374,3 +374,26 @@ def test_gemm_bias_epilogue_equals_broadcast_then_gemm(pkg, oracle, ctx, M, N, K
     np.testing.assert_array_equal(fused.numpy(), two.numpy())
     want = oracle.gemm(X, W, f64acc=True) + b
     assert rowwise_relerr(fused.numpy(), want) <= TOL
+
+
+@pytest.mark.parametrize("d,lpe", [(41, 12), (41, 16), (48, 12), (24, 8), (24, 12), (24, 16), (8, 4), (8, 8), (8, 16), (3, 4), (64, 16)])
+def test_sweep_narrow_forms_every_group_width(pkg, oracle, ctx, force_sweep, monkeypatch, d, lpe):
+    """The narrow-row kernel fetches G = 64 / LPE rows per instruction (LPE = 4, 8, 12, 16 lanes of
+    16 bytes per row); the plan normally picks LPE by padded stream length -- force each legal one."""
+    monkeypatch.setenv("MGGCN_SPMM_NARROW_LPE", str(lpe))
+    n = 1300
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 45_000, 3000, seed=300 + d + lpe)
+    dv = np.random.default_rng(d).standard_normal(dv.shape[0]).astype(np.float32)
+    A, Ao = _csr(pkg, oracle, ip, ix, dv, n)
+    rng = np.random.default_rng(lpe)
+    B = rng.standard_normal((n, d), dtype=np.float32)
+    C0 = rng.standard_normal((n, d), dtype=np.float32)
+    for alpha, beta, flags in [(1.0, 0.0, 0), (0.5, 2.0, 1)]:
+        got, buf = _run_spmm(pkg, ctx, A, B, C0, alpha, beta, flags=flags)
+        assert buf.num_sweep_tasks() > 0
+        want = oracle.spmm(Ao, B, C0.copy(), alpha, beta, f64acc=True)
+        if flags:
+            want = oracle.leaky_relu_forward(want)
+        assert rowwise_relerr(got, want) <= TOL, (d, lpe, alpha, beta)
+    again, _ = _run_spmm(pkg, ctx, A, B, C0, 0.5, 2.0, flags=1)
+    np.testing.assert_array_equal(got, again)                      # reproducible
