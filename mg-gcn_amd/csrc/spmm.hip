@@ -25,6 +25,7 @@
 //  * fp32 FMA accumulation in registers; alpha/beta/leaky-ReLU fused in the
 //    epilogue; beta == 0 never reads C.
 #include <algorithm>
+#include <functional>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -339,8 +340,27 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         // C = beta C + alpha sum_s A[:, slice s] B is evaluated slice after slice: every launch
         // boundary re-synchronises the chip.  Costs one extra read+write of C per extra slice.
         const uint32_t hint_bytes = narrow ? (d_hint + 3) / 4 * 16 : 512u;
+        // Column popularity.  On the Reddit shape the forward matrix (even rows, power-law column
+        // popularity) keeps its hot rows of B in L1/L2 whatever the window and runs best with 6144-row
+        // panels and 64 MiB slices (2.69 ms; 2.74 with 4096 / 32); the backward matrix (power-law rows,
+        // uniformly popular columns) needs the tighter window: 2.86 ms with 4096 / 32 against 3.19
+        // (profiles/experiments/sweep_vs_rowsplit.py, EXP_MATRIX=A).  Measure: share of the non-zeros
+        // that sit in the 1 % most popular columns.
+        bool hot_columns = true;
+        if (n_cols >= 100 && host_indices) {
+            std::vector<uint32_t> cc(n_cols, 0u);
+            const uint64_t nz0 = host_indptr[0], nz1 = host_indptr[n_rows];
+            for (uint64_t e = nz0; e < nz1; e++)
+                if (host_indices[e] < n_cols) cc[host_indices[e]]++;
+            const size_t top = std::max<size_t>(1, n_cols / 100);
+            std::nth_element(cc.begin(), cc.begin() + top, cc.end(), std::greater<uint32_t>());
+            uint64_t hot = 0;
+            for (size_t k = 0; k < top; k++) hot += cc[k];
+            hot_columns = (double)hot >= 0.05 * (double)(nz1 - nz0);
+        }
+        if (const char *hc = std::getenv("MGGCN_SPMM_HOT_COLUMNS")) hot_columns = std::atoi(hc) != 0;
         const uint64_t slice_rows = std::max<uint64_t>(
-            64, env_u32("MGGCN_SPMM_SLICE_ROWS", (uint32_t)(((uint64_t)env_u32("MGGCN_SPMM_SLICE_MIB", 64u) << 20) / hint_bytes)));   // tests set ROWS
+            64, env_u32("MGGCN_SPMM_SLICE_ROWS", (uint32_t)(((uint64_t)env_u32("MGGCN_SPMM_SLICE_MIB", (hot_columns || narrow) ? 64u : 32u) << 20) / hint_bytes)));   // tests set ROWS
         uint32_t S = (uint32_t)std::max<uint64_t>(1, ((uint64_t)n_cols + slice_rows - 1) / slice_rows);
         const uint64_t total_nnz = n_rows ? (uint64_t)host_indptr[n_rows] - host_indptr[0] : 0;
         // The sweep pays only for DENSE rows: its unit of work is a (panel,row) run, and a graph
@@ -349,7 +369,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         // row-split 8.2 ms, sweep 15-38 ms (profiles/experiments/products_like.py).  Gate: mean
         // run length >= 2, and never more slices than leave ~64 non-zeros per (row, slice).
         const double avg_deg = n_rows ? (double)total_nnz / n_rows : 0.0;
-        const double panel_rows = sweep_panel_rows(d_hint);
+        const double panel_rows = sweep_panel_rows(d_hint, hot_columns);
         const double mean_run = n_cols ? avg_deg * std::min<double>(panel_rows, n_cols) / n_cols : 0.0;
         if (!std::getenv("MGGCN_SPMM_SLICE_ROWS")) S = std::max<uint32_t>(1u, std::min<uint32_t>(S, (uint32_t)(avg_deg / 64.0)));
         const bool worth_it = total_nnz >= env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20) &&   // small graphs: row-split is fine
@@ -357,7 +377,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         if (!worth_it) {
             // nothing
         } else if (S <= 1) {
-            if (SweepPlan *sp = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d, true, d_hint))
+            if (SweepPlan *sp = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d, true, d_hint, hot_columns))
                 plan->sweeps.push_back(sp);
         } else {
             // bucket the non-zeros by column slice: two passes over A whatever the slice count
@@ -383,7 +403,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
             bool ok = true;
             for (uint32_t k = 0; k < S && ok; k++) {
                 if (ixs[k].empty()) continue;            // e.g. a rank's own column range in its "remote" matrix
-                SweepPlan *sp = sweep_plan_build(n_rows, n_cols, ips[k].data(), ixs[k].data(), vvs[k].data(), max_d, true, d_hint);
+                SweepPlan *sp = sweep_plan_build(n_rows, n_cols, ips[k].data(), ixs[k].data(), vvs[k].data(), max_d, true, d_hint, hot_columns);
                 if (sp) plan->sweeps.push_back(sp); else ok = false;
                 std::vector<uint32_t>().swap(ixs[k]);        // release as we go
                 std::vector<float>().swap(vvs[k]);

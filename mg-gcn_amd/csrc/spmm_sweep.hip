@@ -589,7 +589,8 @@ uint32_t sweep_lanes_per_entry(uint32_t d_hint) {
     return need <= 4 ? 4u : need <= 8 ? 8u : need <= 12 ? 12u : 16u;
 }
 
-uint32_t sweep_panel_rows(uint32_t d_hint) {
+// hot_columns: a few columns carry much of the matrix (see mggcn_spmm_plan_create_for)
+uint32_t sweep_panel_rows(uint32_t d_hint, bool hot_columns) {
     if (d_hint >= 1 && d_hint <= 64) {
         // 1.5 MiB of B per panel at the 64-byte-multiple pitch: 8192 rows at d = 41 (best of 8192 /
         // 16384 / 32768 on both Reddit matrices), 24576 at d = 16 (16384 beat 8192 there)
@@ -597,7 +598,7 @@ uint32_t sweep_panel_rows(uint32_t d_hint) {
         const uint32_t rows = std::max(1024u, (3u << 19) / pitch / 1024u * 1024u);
         return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS_NARROW", rows));
     }
-    return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 6144u));
+    return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", hot_columns ? 6144u : 4096u));
 }
 
 struct SweepPlan {
@@ -615,7 +616,7 @@ struct SweepPlan {
 
 SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
                             const uint32_t *indices, const float *values, uint32_t max_d, bool force,
-                            uint32_t d_hint) {
+                            uint32_t d_hint, bool hot_columns) {
     if (!n_rows || !indices || !values) return nullptr;
     // narrow form (quad kernel): runs padded to 4 entries, tasks to 16, wider panels (the L2
     // window is counted in bytes: a 176-byte row lets three times as many rows stay resident)
@@ -629,7 +630,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     static_assert(kRW == 16, "4 row bits in the packed entry");
     const uint64_t nnz = (uint64_t)indptr[n_rows] - indptr[0];
     if (!force && nnz < env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20)) return nullptr;   // small graphs: row-split is fine
-    const uint32_t panel_rows = sweep_panel_rows(d_hint);
+    const uint32_t panel_rows = sweep_panel_rows(d_hint, hot_columns);
 
     // resident waves per launch ("round").  Registers would admit 6 blocks of 4 waves per CU
     // (56 VGPRs; ~106 SGPRs -> floor(800 / (ceil(sgpr/16)*16 + 16)) = 6, MI355X_MICROARCH.md

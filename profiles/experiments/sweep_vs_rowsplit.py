@@ -14,7 +14,8 @@ scale = float(os.environ.get("EXP_SCALE", "1.0"))
 n = ip.shape[0] - 1
 A = pkg.csr_matrix(ip, ix, dv, n)
 A.normalize(True)
-A = A.transpose()
+if os.environ.get("EXP_MATRIX", "AT") == "AT":      # forward matrix (even rows, power-law column popularity)
+    A = A.transpose()                              # EXP_MATRIX=A: backward matrix (power-law rows, uniform columns)
 ctx = pkg.context(0)
 widths = [int(x) for x in os.environ.get("EXP_D", "128,41").split(",")]
 panels = [int(x) for x in os.environ.get("EXP_PANELS", "1024,2048,4096").split(",")]
