@@ -26,6 +26,8 @@
 //   are transposed on the LDS write; the others are copied with 16-byte stores.
 // Split-K partial tiles land in a caller-provided slab and are summed in split
 // order by a second kernel (reproducible; no float atomics).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -290,17 +292,21 @@ Split choose_split_thin(uint32_t K) {
     return {(K + chunk - 1) / chunk, chunk};
 }
 
-// Tall reductions: give every CU about two tiles' worth of K-slices.
+// Tall reductions: fill the resident slots (2 workgroups per CU: 168-172 VGPRs) with K-slices, and
+// never exceed them -- 515 blocks on 512 slots run a second round for three blocks
+// (G_W = X^T G, M = 608: 103 slices 687 us, 102 slices 501 us; profiles/experiments/gemm_splits.py).
 Split choose_split(uint32_t M, uint32_t N, uint32_t K) {
     const uint32_t bn = N > 64 ? 128 : 64;
     const uint64_t tiles = (uint64_t)((M + BM - 1) / BM) * ((N + bn - 1) / bn);
     const uint32_t k_steps = (K + BK - 1) / BK;
     uint32_t splits = 1;
     if (tiles < (uint64_t)kNumCU && k_steps >= 16) {
-        const uint32_t want = (uint32_t)((2ull * kNumCU + tiles - 1) / tiles);
+        const uint32_t want = (uint32_t)std::max<uint64_t>(1, (2ull * kNumCU) / tiles);
         splits = std::min<uint32_t>(want, k_steps / 8);   // at least 8 K-steps per slice
         splits = std::max<uint32_t>(splits, 1u);
     }
+    if (const char *e = std::getenv("MGGCN_GEMM_SPLITS"))          // tuning knob (profiles/experiments/gemm_splits.py)
+        splits = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)std::strtoul(e, nullptr, 10), k_steps));
     const uint32_t steps_per = (k_steps + splits - 1) / splits;
     splits = (k_steps + steps_per - 1) / steps_per;
     return {splits ? splits : 1u, steps_per * BK};
