@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--l2")
     ap.add_argument("--main-kernel", default="spmm_vec4_kernel<32, 8, true>")
-    ap.add_argument("--launches-per-unit", type=int, default=1,
+    ap.add_argument("--launches-per-unit", type=float, default=1,
                     help="kernel launches that make up ONE mggcn_spmm_csr_f32 call (sweep form: rounds)")
     a = ap.parse_args()
 
@@ -68,7 +68,7 @@ def main():
                          f"{h or 0:.0f} | {m or 0:.0f} | {hit} |")
         mk = pmc.get(a.main_kernel)
         if mk and "FETCH_SIZE" in mk and "WRITE_SIZE" in mk:
-            traffic = int((2 * mk["FETCH_SIZE"] + mk["WRITE_SIZE"]) * 1024) * a.launches_per_unit
+            traffic = int((2 * mk["FETCH_SIZE"] + mk["WRITE_SIZE"]) * 1024 * a.launches_per_unit)
             json.dump({"kernel": a.main_kernel, "bytes_per_launch": traffic, "source": a.tag,
                        "kernel_launches_per_spmm_call": a.launches_per_unit,
                        "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 per kernel launch x launches per "
