@@ -16,15 +16,23 @@
 //   * a task's non-zeros are stored as ONE stream sorted by (column panel, row): the
 //     wave sweeps the column space panel by panel.  Entry = 8 bytes:
 //     {run_start:1 | row_local:4 | column:27, value}.
-//   * the wave keeps its RW accumulator rows in LDS (RW x 512 B = 8 KiB); runs of
-//     entries with the same row are summed in registers and folded into LDS at the
-//     run boundary (wave-private rows -> plain read-modify-write, no atomics, fixed
-//     order -> bitwise reproducible).
+//   * the wave keeps its RW accumulator rows in REGISTERS (16 rows x 4 planes); a run of
+//     entries with the same row is summed in a small accumulator and added to its row at
+//     the run boundary through the VGPR index mode (wave-uniform row number): no LDS, no
+//     atomics, fixed order -> bitwise reproducible.
 // Because all resident waves start together (one launch per "round" of resident
 // tasks), have equal work and see the same column distribution, they cross each
 // panel at about the same time: the panel is pulled from the Infinity Cache once per
-// XCD and then hit in L2 by ~600 waves.  Placement is a speed matter only; results
+// XCD and then hit in L2 by ~500 waves.  Placement is a speed matter only; results
 // never depend on it.
+//
+// Kernels in this file (dispatch: sweep_launch):
+//   spmm_sweep_pair_kernel        d % 4 == 0, d >= 96: two 512-byte rows per buffer_load_dwordx4
+//   spmm_sweep_quad_lds_kernel<L> d <= 64 (plan built with a width hint): 64/L rows per load,
+//                                 entries staged through LDS
+//   spmm_sweep_kernel<1|2>        every other width / alignment: one row per load
+//   sweep_repack_kernel           B -> 64-byte-multiple pitch for the narrow form
+//   sweep_combine_kernel          partial rows of heavy (sliced) rows, fixed order
 #include <algorithm>
 #include <cmath>
 #include <cstring>
