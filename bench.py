@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; 1.0 = Reddit shape)")
     ap.add_argument("--hidden", type=int, nargs="*", default=[128, 128, 128])
-    ap.add_argument("--mode", default="allgather", choices=["allgather", "rounds"])
+    ap.add_argument("--mode", default="allgather", choices=["allgather", "halo", "rounds"])
     ap.add_argument("--no-overlap", action="store_true", help="the reference's -S flag")
     ap.add_argument("--unfused", action="store_true", help="reference launch sequence, no fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")

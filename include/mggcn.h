@@ -213,6 +213,13 @@ void mggcn_scale_mat_f32(mggcn_stream_t stream, float *mat, float scalar, size_t
  * wrapper copies it back after its own sync (src/gcn.hpp:816-817). */
 void mggcn_abssum_f32(mggcn_stream_t stream, const float *A, size_t size, float *result_device);
 
+/* Halo pack: dst[k, 0:d] = src[indices[k], 0:d] for k < n_indices.
+ * The reference has no counterpart -- its exchange broadcasts whole shards
+ * (src/dist_matrix.hpp:458-467); the rows packed here are the ones its data-prep script counts
+ * as communication volume (test/data/prep.py:237-244).  indices: device, uint32. */
+void mggcn_gather_rows_f32(mggcn_stream_t stream, const float *src, size_t ld_src, const uint32_t *indices,
+                           size_t n_indices, uint32_t d, float *dst, size_t ld_dst);
+
 /* ======================================================================== *
  * Fused tail kernels.  Same math as the chains above,
  * fewer passes over [n x C] / fewer launches.

@@ -8,6 +8,8 @@
 // row kernels give each row to a group of lanes inside a wave64 and reduce with
 // DPP/LDS-crossbar shuffles, grids are sized for 256 CUs.  All of these are HBM
 // passes over [n x m] fp32; none is reshaped into a GEMM.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -386,6 +388,38 @@ MGGCN_API void mggcn_index_log_rows_f32(mggcn_stream_t stream, const float *mat,
     const size_t n_rows = size / m;
     hipLaunchKernelGGL(index_log_rows_kernel, dim3(stream_grid(n_rows)), dim3(256), 0, as_stream(stream),
                        mat, indices, values, n_rows, m);
+    MGGCN_CHECK_LAUNCH();
+}
+
+namespace {
+// Halo pack: dst[k, :] = src[idx[k], :].  One wave64 per gathered row, float4 lanes where the
+// pitches allow; a pure HBM stream (the rows a peer rank needs of this rank's shard).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, size_t ld_src,
+                                                          const uint32_t *__restrict__ idx, size_t n_idx, uint32_t d,
+                                                          float *__restrict__ dst, size_t ld_dst, bool vec) {
+    const int lane = threadIdx.x & 63;
+    const size_t waves = (size_t)gridDim.x * (blockDim.x >> 6);
+    for (size_t k = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < n_idx; k += waves) {
+        const float *s = src + (size_t)idx[k] * ld_src;
+        float *o = dst + k * ld_dst;
+        if (vec) {
+            for (uint32_t c = lane * 4; c < d; c += 256)
+                *reinterpret_cast<float4 *>(o + c) = *reinterpret_cast<const float4 *>(s + c);
+        } else {
+            for (uint32_t c = lane; c < d; c += 64) o[c] = s[c];
+        }
+    }
+}
+}  // namespace
+
+MGGCN_API void mggcn_gather_rows_f32(mggcn_stream_t stream, const float *src, size_t ld_src, const uint32_t *indices,
+                                     size_t n_indices, uint32_t d, float *dst, size_t ld_dst) {
+    if (!n_indices || !d) return;
+    MGGCN_REQUIRE(src && indices && dst && ld_src >= d && ld_dst >= d, "gather_rows: bad operand");
+    const bool vec = d % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && aligned16(src) && aligned16(dst);
+    const size_t blocks = std::min<size_t>((n_indices + 3) / 4, (size_t)kNumCU * 16);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, ld_src, indices,
+                       n_indices, d, dst, ld_dst, vec);
     MGGCN_CHECK_LAUNCH();
 }
 

@@ -24,6 +24,12 @@ src/cuda_utils.hpp:61-89).  Two modes:
     block cut by piece with renumbered columns): the SpMM over piece c overlaps the
     transfer of piece c+1.
     C_j = A[j,j].B_j + sum_{i!=j} A[j,i].B_i  -- the reference's sum, regrouped.
+``halo``: the same split, but every rank sends each peer only the rows of its shard that the
+    peer's blocks reference (index lists built at partition time, packed by a gather kernel,
+    exchanged with ONE all-to-all of variable-size pieces, remote block renumbered to the
+    receive layout).  On a graph where every rank touches every row (the random synthetic
+    Reddit) this moves what the all-gather moves; on a partitioned sparse graph it moves the
+    boundary only.
 ``rounds``: the reference's schedule, one broadcast + one block SpMM per round i,
     double-buffered, accumulating in round order (used for order-exact parity tests
     and as the `-S`-style baseline).
@@ -149,6 +155,52 @@ def split_remote_chunks(remote: csr_matrix, P: int, rows: int, K: int) -> List[c
     return out
 
 
+def halo_need_lists(blocks: List[csr_matrix], r: int) -> List[np.ndarray]:
+    """need[s] = sorted distinct rows of rank s's shard that the blocks A[{r, s}] of rank r reference
+    (block-local column indices); empty for s == r."""
+    return [np.unique(b.indices).astype(np.uint32) if s != r else np.empty(0, dtype=np.uint32)
+            for s, b in enumerate(blocks)]
+
+
+def halo_volume_matrix(A: csr_matrix, P: int) -> np.ndarray:
+    """V[i, j] = distinct rows of shard j that rank i's row block references (i != j): the
+    communication volume in rows per exchange of mode="halo", the matrix the reference's data-prep
+    script prints for a partition (test/data/prep.py:237-244).  The all-gather form moves
+    (P - 1) * n / P rows into every rank whatever the graph."""
+    p = partition_bounds(A.n(), P)
+    V = np.zeros((P, P), dtype=np.int64)
+    for i in range(P):
+        blocks = split_row_block(A, p[i], p[i + 1], p)
+        for j, x in enumerate(halo_need_lists(blocks, i)):
+            V[i, j] = len(x)
+    return V
+
+
+def merge_blocks_halo(blocks: List[csr_matrix], need: List[np.ndarray], r: int) -> csr_matrix:
+    """The remote blocks of one row block merged into one CSR whose columns index the RECEIVE
+    buffer of the halo exchange: pieces in source-rank order, piece s holding need[s] in order.
+    Row order and in-row order (source rank, then original order) are kept."""
+    rows = blocks[0].n()
+    off = np.zeros(len(blocks) + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in need], out=off[1:])
+    lens = [np.diff(b.indptr.astype(np.int64)) if s != r else np.zeros(rows, dtype=np.int64) for s, b in enumerate(blocks)]
+    indptr = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(np.sum(lens, axis=0), out=indptr[1:])
+    nnz = int(indptr[-1])
+    indices = np.empty(nnz, dtype=np.uint32)
+    data = np.empty(nnz, dtype=np.float32)
+    start = indptr[:-1].copy()
+    for s, b in enumerate(blocks):
+        if s == r or b.nnz() == 0:
+            continue
+        ln = lens[s]
+        pos = np.repeat(start, ln) + (np.arange(int(ln.sum())) - np.repeat(b.indptr[:-1].astype(np.int64), ln))
+        indices[pos] = (off[s] + np.searchsorted(need[s], b.indices)).astype(np.uint32)
+        data[pos] = b.data
+        start = start + ln
+    return csr_matrix(indptr.astype(np.uint32), indices, data, int(off[-1]))
+
+
 # --------------------------------------------------------------------------------------
 # host-staged collectives (gloo): CPU rehearsal of the exchange step and the fallback when
 # several ranks share one GPU.  Pure torch.distributed on CPU tensors -- no GPU needed.
@@ -255,6 +307,21 @@ class dist_context:
                 off += t.numel()
 
 
+    def all_to_all_rows(self, send, recv, send_rows: Sequence[int], recv_rows: Sequence[int], stream_id: int):
+        """Variable-size row exchange: rows [sum(send_rows[:s]), +send_rows[s]) of ``send`` go to rank s,
+        ``recv`` receives recv_rows[s] rows from rank s, in rank order."""
+        torch, dist = _torch(), _dist()
+        if self._nccl():
+            with torch.cuda.stream(self.ctx.cuda_streams[stream_id]):
+                work = dist.all_to_all_single(recv, send, list(recv_rows), list(send_rows), group=self.group,
+                                              async_op=True)
+            return _Pending(self, work, None, None)
+        self.ctx.cuda_streams[0].synchronize()
+        self.ctx.cuda_streams[stream_id].synchronize()
+        host_out = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(host_out, send.detach().cpu(), list(recv_rows), list(send_rows), group=self.group)
+        return _Pending(self, None, host_out, recv)
+
     def all_reduce_sum_async(self, flat, after_stream_id: int = 0):
         """In-place sum over ranks of ONE flat tensor on the comm stream, ordered after the work
         already queued on ``after_stream_id``; returns a handle whose .wait(stream_id) orders the
@@ -352,6 +419,28 @@ class dist_row_csr_matrix:
         K = max(1, min(K, rows))
         self.chunk_bounds = chunk_bounds(rows, K)
         self.remote_chunks = split_remote_chunks(self.remote, dctx.P, rows, K)
+        self._full, self._rank, self._P = A, r, dctx.P
+        self.halo = None
+
+    def build_halo(self, device) -> "dist_row_csr_matrix":
+        """Index lists and the renumbered remote block of the halo exchange (mode="halo").  Every rank
+        holds the whole matrix here (it generated or read it), so the lists of what the PEERS need of
+        this rank's shard are computed locally: the distinct columns of block A[{s, r}]."""
+        if self.halo is not None:
+            return self
+        torch = _torch()
+        r, P, p = self._rank, self._P, self.p
+        need = halo_need_lists(self.blocks, r)
+        send = [np.unique(split_row_block(self._full, p[s], p[s + 1], p)[r].indices).astype(np.uint32) if s != r
+                else np.empty(0, dtype=np.uint32) for s in range(P)]
+        send_idx = np.concatenate(send) if P > 1 else np.empty(0, dtype=np.uint32)
+        self.halo = {
+            "recv_rows": [int(len(x)) for x in need],
+            "send_rows": [int(len(x)) for x in send],
+            "send_idx": torch.from_numpy(send_idx.astype(np.int64)).to(torch.int32).to(device),   # uint32 bits
+            "remote": merge_blocks_halo(self.blocks, need, r),
+        }
+        return self
 
     def n(self): return self.N_
     def m(self): return self.M_
@@ -367,6 +456,7 @@ class dist_sparse_linear:
         self.bcast = [bcast_buffer, bcast_buffer2]
         self.mode = mode
         self.plans = {}
+        self._halo_send = None
 
     def _plan(self, ctx: context, key, M: csr_matrix, d: int):
         pl = self.plans.get(key)
@@ -409,6 +499,27 @@ class dist_sparse_linear:
                     blk = A.remote_chunks[c]
                     ops._spmm(ctx, blk, gathered[c], C.local, self._plan(ctx, (tag, "remote", c), blk, d), 1.0,
                               1.0, flags if c == K - 1 else 0)
+        elif self.mode == "halo":
+            h = A.build_halo(ctx.device).halo
+            n_send, n_recv = sum(h["send_rows"]), sum(h["recv_rows"])
+            if self._halo_send is None or self._halo_send.numel() < max(n_send, 1) * d:
+                self._halo_send = torch.empty(max(n_send, 1) * d, dtype=torch.float32, device=ctx.device)
+            send = dn_matrix(max(n_send, 1), d, self._halo_send)
+            recv = dn_matrix(max(n_recv, 1), d, self.bcast[0])
+            ops.gather_rows(ctx, B.local, h["send_idx"], send)            # pack on the compute stream
+            ctx.record(name + "0_matmul-halo-packed", 0)
+            ctx.wait(name + "0_matmul-halo-packed", cs)
+            ctx.record(name + "0_matmul-bcast-start", cs)
+            pend = None
+            if P > 1:
+                pend = dctx.all_to_all_rows(send.t[:n_send], recv.t[:n_recv], h["send_rows"], h["recv_rows"], cs)
+            ops._spmm(ctx, A.diag, B.local, C.local, self._plan(ctx, (tag, "diag"), A.diag, d), 1.0, beta,
+                      flags if P == 1 else 0)
+            if P > 1:
+                pend.wait(0)
+                ctx.record(name + "0_matmul-bcast-finish", 0)
+                blk = h["remote"]
+                ops._spmm(ctx, blk, recv, C.local, self._plan(ctx, (tag, "halo"), blk, d), 1.0, 1.0, flags)
         else:  # reference schedule: round i = broadcast shard i || SpMM with block (r, i)
             bufs = [dn_matrix(rows, d, self.bcast[0]), dn_matrix(rows, d, self.bcast[1])]
             for i in range(P):
@@ -661,7 +772,7 @@ class dist_gcn:
         self.HW_buffer = torch.empty(nmax * max_d // P, dtype=torch.float32, device=dev)
         # all-gather mode keeps the whole gathered B resident (n x max_d: 119 MB on Reddit,
         # nothing next to 288 GB); rounds mode needs the reference's two shard-sized buffers
-        big = nmax * max_d if mode == "allgather" else nmax * max_d // P
+        big = nmax * max_d if mode in ("allgather", "halo") else nmax * max_d // P
         self.bcast_buffer = torch.empty(big, dtype=torch.float32, device=dev)
         self.bcast_buffer2 = torch.empty(nmax * max_d // P, dtype=torch.float32, device=dev)
         self.layers_: List[dist_gcn_layer] = []

@@ -96,6 +96,14 @@ def linear_forward(ctx: context, X: dn_matrix, W: dn_matrix, b: dn_matrix, XW: d
                                 b.buffer(), XW.buffer(), XW.m(), ws.data_ptr() if ws is not None else None, ws_bytes)
 
 
+def gather_rows(ctx: context, src: dn_matrix, indices, dst: dn_matrix, stream_id: int = 0) -> None:
+    """dst[k, :] = src[indices[k], :] (halo pack; indices: device uint32 tensor viewed as int32 storage)"""
+    n_idx = int(indices.numel())
+    _req(dst.n() >= n_idx and dst.m() == src.m(), "gather_rows shape")
+    ctx.lib.mggcn_gather_rows_f32(ctx.stream(stream_id), src.buffer(), src.m(), indices.data_ptr(), n_idx, src.m(),
+                                  dst.buffer(), dst.m())
+
+
 # ---- element-wise / row kernels: src/cuda_utils.hpp:470-748 wrappers -----------------
 def leaky_relu_forward(ctx: context, in_: dn_matrix, out: dn_matrix, alpha: float = 0.01) -> None:
     _req(in_.shape() == out.shape(), "shape mismatch")

@@ -66,6 +66,19 @@ def _worker(rank, P, port, n, d, out_q):
                 orc.spmm(as_o(blk), piece, acc, 1.0, 1.0)
             Cc[K] = acc
 
+        # halo exchange: every peer gets only the rows of this shard its blocks reference
+        need = D.halo_need_lists(blocks, rank)
+        send = [np.unique(D.split_row_block(A, p[s], p[s + 1], p)[rank].indices) if s != rank else np.empty(0, np.int64)
+                for s in range(P)]
+        sendbuf = torch.cat([mine[torch.from_numpy(np.asarray(x, dtype=np.int64))] for x in send]) if P > 1 else mine[:0]
+        recvbuf = torch.empty((sum(len(x) for x in need), d), dtype=torch.float32)
+        dist.all_to_all_single(recvbuf, sendbuf.contiguous(), [len(x) for x in need], [len(x) for x in send])
+        Hh = orc.spmm(as_o(diag), mine.numpy())
+        merged = D.merge_blocks_halo(blocks, need, rank)
+        assert merged.m() == recvbuf.shape[0] and merged.nnz() == remote.nnz()
+        orc.spmm(as_o(merged), recvbuf.numpy(), Hh, 1.0, 1.0)
+        halo_rows = recvbuf.shape[0]
+
         # the reference's rounds: broadcast shard i, multiply block (rank, i), accumulate in order
         R = np.empty_like(C)
         for i in range(P):
@@ -76,7 +89,7 @@ def _worker(rank, P, port, n, d, out_q):
         G = rng.standard_normal((n, 5)).astype(np.float32)
         gw = torch.from_numpy(orc.gemm(B[p[rank]:p[rank + 1]], G[p[rank]:p[rank + 1]], A_T=True))
         gw = D.gloo_all_reduce_sum(gw.reshape(-1)).reshape(d, 5).numpy()
-        out_q.put((rank, C, R, gw, Cc))
+        out_q.put((rank, C, R, gw, Cc, Hh, halo_rows))
     finally:
         dist.destroy_process_group()
 
@@ -108,8 +121,10 @@ def test_partition_and_exchange_match_single_process(oracle, pkg, P):
     G.standard_normal((n, d))
     Gm = G.standard_normal((n, 5)).astype(np.float32)
     gw_full = oracle.gemm(B, Gm, A_T=True, f64acc=True)
-    for rank, C, R, gw, Cc in res:
+    for rank, C, R, gw, Cc, Hh, halo_rows in res:
         np.testing.assert_allclose(C, full[p[rank]:p[rank + 1]], rtol=1e-5, atol=1e-6)     # regrouped sum
+        np.testing.assert_array_equal(Hh, C)           # halo: same products in the same order as the all-gather form
+        assert 0 < halo_rows <= n - n // P
         for K in (2, 3):
             np.testing.assert_allclose(Cc[K], full[p[rank]:p[rank + 1]], rtol=1e-5, atol=1e-6)
         np.testing.assert_array_equal(R, rounds[rank])                                      # same order: bit-exact
@@ -159,3 +174,22 @@ def test_remote_chunks_reassemble(pkg):
                     cols = np.concatenate([np.arange(s * rows + cb[c], s * rows + cb[c + 1]) for s in range(P)])
                     np.testing.assert_array_equal(blk.as_dn(), dense[:, cols])
     assert D.default_chunks(1) == 1 and D.default_chunks(2) == 1 and D.default_chunks(8) >= 2
+
+
+def test_halo_volume_follows_the_cut(pkg):
+    """mode="halo" moves the boundary only: a graph of P dense communities with a few cross edges
+    needs a handful of rows per peer; the random graph needs (almost) every row of every shard."""
+    import scipy.sparse as sp
+    D = pkg.dist
+    n, P = 64, 4
+    rows = n // P
+    comm = sp.block_diag([sp.random(rows, rows, density=0.5, format="csr", dtype=np.float32, random_state=k) for k in range(P)])
+    cross = sp.csr_matrix((np.ones(3, np.float32), ([1, 20, 40], [17, 3, 63])), shape=(n, n))
+    M = sp.csr_matrix(comm + cross + sp.eye(n, dtype=np.float32))
+    A = pkg.csr_matrix(M.indptr.astype(np.uint32), M.indices.astype(np.uint32), M.data, n)
+    V = D.halo_volume_matrix(A, P)
+    assert V.sum() == 3 and V[0, 1] == 1 and V[1, 0] == 1 and V[2, 3] == 1 and (np.diag(V) == 0).all()
+    ip, ix, dv = _graph(n, 5)
+    V2 = D.halo_volume_matrix(pkg.csr_matrix(ip, ix, dv, n), P)
+    off = V2[~np.eye(P, dtype=bool)]
+    assert (off >= 0.6 * rows).all() and (off <= rows).all()

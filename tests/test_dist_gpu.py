@@ -66,7 +66,7 @@ def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo", chu
 
 
 @pytest.mark.parametrize("P,mode,chunks", [(2, "allgather", None), (2, "rounds", None), (3, "allgather", None),
-                                           (2, "allgather", 3), (4, "allgather", 2)])
+                                           (2, "allgather", 3), (4, "allgather", 2), (2, "halo", None), (3, "halo", None)])
 def test_dist_gcn_matches_oracle(oracle, P, mode, chunks):
     n, F, C, hidden, epochs = 1536, 20, 5, [16, 16], 2
     ctx = mp.get_context("spawn")
@@ -101,7 +101,7 @@ def test_dist_gcn_matches_oracle(oracle, P, mode, chunks):
         assert res[r][1][0][0] == res[0][1][0][0]                           # same global loss on every rank
 
 
-@pytest.mark.parametrize("mode", ["allgather", "rounds"])
+@pytest.mark.parametrize("mode", ["allgather", "rounds", "halo"])
 def test_dist_gcn_over_rccl_single_rank(oracle, mode):
     """The RCCL transport itself (backend "nccl": all_gather_into_tensor / broadcast / all_reduce on
     the comm stream, stream-level waits) with the one rank a one-GPU box allows; the multi-rank

@@ -397,3 +397,18 @@ def test_sweep_narrow_forms_every_group_width(pkg, oracle, ctx, force_sweep, mon
         assert rowwise_relerr(got, want) <= TOL, (d, lpe, alpha, beta)
     again, _ = _run_spmm(pkg, ctx, A, B, C0, 0.5, 2.0, flags=1)
     np.testing.assert_array_equal(got, again)                      # reproducible
+
+
+@pytest.mark.parametrize("d", [128, 41, 3])
+def test_gather_rows_packs_the_halo(pkg, ctx, d):
+    import torch
+    rng = np.random.default_rng(d)
+    src = rng.standard_normal((5000, d)).astype(np.float32)
+    idx = rng.integers(0, 5000, size=1777).astype(np.int64)
+    S = pkg.dn_matrix.from_numpy(src)
+    D = pkg.dn_matrix.from_numpy(np.full((1777, d), np.nan, dtype=np.float32))
+    dev_idx = torch.from_numpy(idx).to(torch.int32).to(ctx.device)
+    pkg.ops.gather_rows(ctx, S, dev_idx, D)
+    ctx.sync()
+    np.testing.assert_array_equal(D.numpy(), src[idx])
+    pkg.ops.gather_rows(ctx, S, dev_idx[:0], D)          # empty list: no-op
