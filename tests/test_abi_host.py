@@ -235,3 +235,24 @@ def test_reserved_accumulator_registers_are_left_alone_by_the_compiler(tmp_path)
         blk = blk[:blk.index(".wavefront_size")] if ".wavefront_size" in blk else blk[:2000]
         assert re.search(r"\.vgpr_count:\s+128\b", blk), (name, blk[:400])
         assert re.search(r"\.private_segment_fixed_size:\s+0\b", blk), (name, blk[:400])
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """include/mggcn_comm.h (the single-process multi-GPU exchange the C++ host layer links): every
+    declared entry point is exported by libmggcn_comm.so.  Symbols are read from the ELF dynamic
+    table -- loading the library would pull in RCCL and touch the GPU runtime."""
+    text = open(os.path.join(ROOT, "include", "mggcn_comm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mggcn_comm_[a-z0-9_]+)\s*\(", text)))
+    assert len(names) == 6, names
+    lib = os.path.join(ROOT, "mg-gcn_amd", "lib", "libmggcn_comm.so")
+    assert os.path.exists(lib), "build() must produce libmggcn_comm.so"
+    nm = None
+    for tool in ("nm", "/opt/rocm/lib/llvm/bin/llvm-nm"):
+        r = subprocess.run([tool, "-D", "--defined-only", lib], capture_output=True, text=True)
+        if r.returncode == 0:
+            nm = r.stdout
+            break
+    assert nm is not None, "no nm tool"
+    exported = set(re.findall(r"\b(mggcn_comm_[a-z0-9_]+)\b", nm))
+    assert not [n for n in names if n not in exported], (names, sorted(exported))
