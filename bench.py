@@ -69,11 +69,20 @@ def main():
     P = world
     pkg = ge.load_package()
     pkg._lib.require_gpu()                     # loud: there is no CPU path
+    # Rehearsal on a one-GPU box: MGGCN_BENCH_REHEARSAL=1 maps every rank to cuda:0 and exchanges
+    # through gloo (RCCL refuses two ranks on one device).  Exercises this file's N > 1 code path;
+    # its numbers mean nothing.
+    rehearsal = os.environ.get("MGGCN_BENCH_REHEARSAL", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if P > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- workload ------------------------------------------------------------------
     t_gen = time.time()
@@ -151,7 +160,7 @@ def main():
     t1 = time.perf_counter()
     ms = (t1 - t0) * 1000.0 / max(args.steps, 1)
     if P > 1:
-        t = torch.tensor([ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([ms], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
 
