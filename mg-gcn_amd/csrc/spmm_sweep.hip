@@ -898,9 +898,11 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
                       (reinterpret_cast<uintptr_t>(B) & 7u) == 0 && (reinterpret_cast<uintptr_t>(C) & 7u) == 0;
     const uint32_t b_bytes = (uint32_t)((uint64_t)p->n_cols * ldb * sizeof(float));
     const uint32_t row_bytes = (uint32_t)(ldb * sizeof(float));
-    // narrow rows (one column per lane, <= 256 B per gather) are instruction-bound rather than
-    // L2-window-bound: twice the resident waves per round measured faster (d = 41: 2.4 -> 2.0 ms)
-    const uint32_t per_launch = (vec2 || vec4) ? p->round_tasks : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
+    // One launch = one round of RESIDENT tasks for the float4 kernels (128 VGPRs: four blocks of four
+    // waves per CU; six blocks per launch left a third of the waves queued behind the others and out
+    // of step: d = 41 1.64 / 1.71 ms against 1.52 / 1.55).  The one-column-per-lane kernels (56 VGPRs)
+    // are instruction-bound and take six blocks per CU (d = 41: 2.4 -> 2.0 ms).
+    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
     for (uint32_t t0 = 0; t0 < p->n_tasks; t0 += per_launch) {
         const uint32_t n_launch = std::min(per_launch, p->n_tasks - t0);
         const dim3 grid((n_launch + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
