@@ -653,10 +653,12 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     const uint32_t blocks_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u), 8u));
     const uint32_t round_tasks = kNumCU * blocks_per_cu * kWavesPerBlock;
 
+    // (MGGCN_SPMM_SWEEP_ROWS_PER_TASK caps it for experiments: 8 rows per wave -- twice the launches,
+    //  same slices -- ran 2.88 ms against 2.69 at 16, 4 rows 3.00: profiles/experiments/sweep_rows_per_task_r01.log)
     // 1. virtual rows: slices of heavy rows get partial-sum slots
     // rows per task: 16 when there are enough rows to fill a round, fewer for small row blocks
     // (a rank's share at P = 8 has 29 k rows: 16 rows per wave would leave 7 waves per CU)
-    const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)kRW, (n_rows + round_tasks - 1) / round_tasks));
+    const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t)kRW, std::max(1u, env_u32("MGGCN_SPMM_SWEEP_ROWS_PER_TASK", (uint32_t)kRW))), (n_rows + round_tasks - 1) / round_tasks));
     const uint32_t t_est = (n_rows + cap_rows - 1) / cap_rows;
     const uint32_t target = (uint32_t)std::max<uint64_t>(1, nnz / t_est);
     const uint32_t split = std::max<uint32_t>(256u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_SPLIT", target / 2), 1u << 20));
