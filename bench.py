@@ -101,12 +101,8 @@ def main():
         Xd, Yd = pkg.dn_matrix.from_numpy(X), pkg.dn_matrix.from_numpy(Y)
         fwd_mats = {"0_": G.A_T}                             # forward SpMM operand (for byte counts)
 
-        def epoch():
-            loss, acc = G.train_forward(ctx, Xd, Yd)
-            G.backward(ctx)
-            G.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
-            ctx.sync()
-            return loss, acc
+        def epoch():          # forward + loss + backward + Adam + sync (src/main.cpp:122-129), one host sync
+            return G.train_step(ctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
         spmm_shape = (G.A_T.n(), G.A_T.m(), G.A_T.nnz())
     else:
         D = pkg.dist
@@ -122,11 +118,7 @@ def main():
         Yd = D.dist_row_dn_matrix(dctx, Y)
 
         def epoch():
-            loss, acc = G.train_forward(dctx, Xd, Yd)
-            G.backward(dctx)
-            G.adam_update(dctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
-            dctx.sync()
-            return loss, acc
+            return G.train_step(dctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
         spmm_shape = (A_Td.diag.n(), n, A_Td.diag.nnz() + A_Td.remote.nnz())
     t_gen = time.time() - t_gen
 

@@ -732,11 +732,19 @@ class dist_row_softmax_cross_entropy_loss:
     def __init__(self, name: str, copy: bool = True, fused: bool = False):
         self.inner = softmax_cross_entropy_loss(name, copy, fused)
 
-    def __call__(self, dctx: dist_context, H: dist_row_dn_matrix, Y: dist_row_dn_matrix):
-        dist = _dist()
+    def __call__(self, dctx: dist_context, H: dist_row_dn_matrix, Y: dist_row_dn_matrix, sync: bool = True):
         self.inner(dctx.ctx, H.local, Y.local, n_global=Y.n(), sync=False)
         self._G = _wrap_local(self.inner.G, H.n())
+        self._n = H.n()
+        if not sync:
+            return None
         dctx.sync()                                   # the reference blocks here too (:928)
+        return self.read(dctx)
+
+    def read(self, dctx: dist_context):
+        """global (loss, acc) of the last call; the caller has synchronised"""
+        dist = _dist()
+        H_n = self._n
         if dctx.backend == "nccl":
             sums = self.inner.sums.clone()
             dist.all_reduce(sums, group=dctx.group)
@@ -745,7 +753,7 @@ class dist_row_softmax_cross_entropy_loss:
             sums = self.inner.sums.detach().cpu()
             dist.all_reduce(sums, group=dctx.group)
         s = sums.numpy()
-        n = np.float32(H.n())
+        n = np.float32(H_n)
         return float(np.float32(s[0]) / n), float(np.float32(s[1]) / n)
 
     def backward(self) -> dist_row_dn_matrix:
@@ -800,5 +808,16 @@ class dist_gcn:
     def adam_update(self, dctx, lr, beta1, beta2, weight_decay, eps) -> None:
         for layer in self.layers_:
             layer.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
+
+    def train_step(self, dctx: dist_context, H: dist_row_dn_matrix, Y: dist_row_dn_matrix, lr, beta1, beta2,
+                   weight_decay, eps):
+        """forward + loss + backward + Adam with ONE host synchronisation and the loss all-reduce at the
+        end of the epoch (see gcn.train_step); the reference's loop body is src/main.cpp:159-166."""
+        out = self(dctx, H)
+        self.loss_layer(dctx, out, Y, sync=False)
+        self.backward(dctx)
+        self.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
+        dctx.sync()
+        return self.loss_layer.read(dctx)
 
     def layers(self): return self.layers_

@@ -305,11 +305,17 @@ class softmax_cross_entropy_loss:
             ops.abssum(ctx, self.T, self.sums[1:2])
         ctx.record(n + "1_loss-layer", 0)
         ctx.register_timer(n + "loss-layer", n + "0_loss-layer", n + "1_loss-layer")
+        self._n = H.n()
         if not sync:
             return None
         ctx.sync()
+        return self.read(ctx)
+
+    def read(self, ctx: context):
+        """(loss, acc) of the last call; the caller has synchronised (train_step reads after the
+        whole epoch is done instead of blocking between forward and backward)."""
         s = self.sums.cpu().numpy()
-        return float(np.float32(s[0]) / np.float32(H.n())), float(np.float32(s[1]) / np.float32(H.n()))
+        return float(np.float32(s[0]) / np.float32(self._n)), float(np.float32(s[1]) / np.float32(self._n))
 
     def backward(self) -> dn_matrix:
         return self.G
@@ -352,6 +358,19 @@ class gcn:
         G = self.loss_layer.backward()
         for layer in reversed(self.layers_):
             G = layer.backward(ctx, G)
+
+    def train_step(self, ctx: context, H: dn_matrix, Y: dn_matrix, lr: float, beta1: float, beta2: float,
+                   weight_decay: float, eps: float):
+        """One epoch = the reference's loop body (src/main.cpp:122-129: train_forward, backward,
+        adam_update, sync) with ONE host synchronisation: the loss / accuracy scalars are read after
+        the epoch's last kernel instead of between forward and backward (the reference blocks inside
+        its loss layer, src/gcn.hpp:816-817, and leaves the GPU idle while the host catches up)."""
+        out = self(ctx, H)
+        self.loss_layer(ctx, out, Y, sync=False)
+        self.backward(ctx)
+        self.adam_update(ctx, lr, beta1, beta2, weight_decay, eps)
+        ctx.sync()
+        return self.loss_layer.read(ctx)
 
     def update(self, ctx: context, lr: float, weight_decay: float) -> None:
         for layer in self.layers_:

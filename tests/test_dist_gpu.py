@@ -52,7 +52,11 @@ def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo", chu
                        sizes, fused=True, mode=mode)
         Xd, Yd = D.dist_row_dn_matrix(dctx, X), D.dist_row_dn_matrix(dctx, Y)
         out = []
-        for _ in range(epochs):
+        for ep in range(epochs):
+            if ep == epochs - 1 and epochs > 1:         # last epoch through the one-sync step
+                loss, acc = G.train_step(dctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+                out.append((loss, acc, [l.GW().local.numpy().copy() for l in G.layers()]))
+                continue
             loss, acc = G.train_forward(dctx, Xd, Yd)
             G.backward(dctx)
             dctx.sync()

@@ -275,3 +275,25 @@ def test_evaluate_per_split_accuracy(pkg, oracle, ctx):
             assert abs(res[name] - want) <= 2.0 / m.sum()      # argmax ties under 1e-4 fp noise
     tot = sum(res[k] * (S.reshape(-1) == i).sum() for i, k in enumerate(["train", "val", "test"]))
     assert abs(tot / n - res["all"]) < 1e-6
+
+
+def test_train_step_equals_the_three_calls(pkg, ctx):
+    """gcn.train_step (one host sync, loss read at the end of the epoch) == train_forward + backward +
+    adam_update + sync (the reference's loop body, src/main.cpp:122-129): same kernels in the same
+    order: bitwise equal weights; the loss scalars are float atomic sums over workgroups (order-free),
+    equal to rounding."""
+    n, sizes = 2048, [24, 16, 16, 5]
+    ip, ix, dv = pkg.datasets.synth_uniform_csr(n, 8, seed=9)
+    rng = np.random.default_rng(10)
+    X = pkg.dn_matrix.from_numpy(rng.standard_normal((n, 24)).astype(np.float32))
+    Y = pkg.dn_matrix.from_numpy(rng.integers(0, 5, size=(n, 1)).astype(np.int32))
+    Ga = pkg.gcn(pkg.csr_matrix(ip, ix, dv.copy(), n), sizes)
+    Gb = pkg.gcn(pkg.csr_matrix(ip, ix, dv.copy(), n), sizes)
+    for _ in range(3):
+        la = Ga.train_step(ctx, X, Y, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+        lb = Gb.train_forward(ctx, X, Y)
+        Gb.backward(ctx); Gb.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8); ctx.sync()
+        assert abs(la[0] - lb[0]) <= 2e-6 * abs(lb[0]) and la[1] == lb[1]
+    for a, b in zip(Ga.layers(), Gb.layers()):
+        np.testing.assert_array_equal(a.W().numpy(), b.W().numpy())
+        np.testing.assert_array_equal(a.b().numpy(), b.b().numpy())
