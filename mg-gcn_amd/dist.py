@@ -115,13 +115,15 @@ def split_local_remote(A: csr_matrix, row_begin: int, row_end: int) -> Tuple[csr
 def default_chunks(P: int) -> int:
     """Pieces the exchange of one SpMM is cut into (all-gather mode).  With one piece only the
     diagonal block (1/P of the work) overlaps the exchange; with K pieces the SpMM over piece c
-    runs while piece c+1 is still on the wire.  P <= 2: the diagonal block already covers the
-    transfer.  Override with MGGCN_DIST_CHUNKS."""
+    runs while piece c+1 is still on the wire.  Two pieces at P = 2 (one xGMI link between the pair:
+    60 MB per exchange is of the order of the diagonal block's 0.7 ms, so half the remote block should
+    start early), four from P = 3 on (the cut costs no compute: -1 % / -7 % at P = 4 / 8,
+    profiles/experiments/rank_share.py).  Override with MGGCN_DIST_CHUNKS."""
     import os
     env = os.environ.get("MGGCN_DIST_CHUNKS")
     if env:
         return max(1, int(env))
-    return 1 if P <= 2 else (2 if P <= 4 else 4)
+    return 1 if P <= 1 else (2 if P == 2 else 4)
 
 
 def chunk_bounds(rows: int, K: int) -> List[int]:

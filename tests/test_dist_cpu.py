@@ -173,7 +173,7 @@ def test_remote_chunks_reassemble(pkg):
                     assert (blk.n(), blk.m()) == (rows, P * ln)
                     cols = np.concatenate([np.arange(s * rows + cb[c], s * rows + cb[c + 1]) for s in range(P)])
                     np.testing.assert_array_equal(blk.as_dn(), dense[:, cols])
-    assert D.default_chunks(1) == 1 and D.default_chunks(2) == 1 and D.default_chunks(8) >= 2
+    assert D.default_chunks(1) == 1 and D.default_chunks(2) == 2 and D.default_chunks(8) == 4
 
 
 def test_halo_volume_follows_the_cut(pkg):
