@@ -463,10 +463,7 @@ class dist_sparse_linear:
     def _plan(self, ctx: context, key, M: csr_matrix, d: int):
         pl = self.plans.get(key)
         if pl is None:
-            ctx.set()
-            pl = self.plans[key] = ops.spmm_buffer(
-                ctx.lib, ctx.lib.mggcn_spmm_plan_create_for(M.n(), M.m(), M.indptr.ctypes.data, M.indices.ctypes.data,
-                                                             M.data.ctypes.data, max(d, 128), d))
+            pl = self.plans[key] = ops.spmm_plan_for(ctx, M, max(d, 128), d)     # shared across layers
         return pl
 
     def _run(self, dctx: dist_context, A: dist_row_csr_matrix, tag: str, B: dist_row_dn_matrix,

@@ -7,6 +7,8 @@ Shape preconditions the reference only ``assert``s raise ``ValueError`` here.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 from .matrix import context, csr_matrix, dn_matrix
@@ -23,6 +25,7 @@ class spmm_buffer:
 
     def __init__(self, lib, handle: int):
         self.lib, self.handle = lib, handle
+        self.max_d = 0
 
     def num_items(self) -> int: return self.lib.mggcn_spmm_plan_num_items(self.handle)
     def num_split_rows(self) -> int: return self.lib.mggcn_spmm_plan_num_split_rows(self.handle)
@@ -43,10 +46,25 @@ def get_matmul_buffer(ctx: context, A: csr_matrix, B: dn_matrix, C: dn_matrix, a
     """reference src/cuda_utils.hpp:94-102"""
     _req(A.m() == B.n(), "A.m() != B.n()")
     _req(A.n() == C.n() and B.m() == C.m(), "C shape mismatch")
-    ctx.set()
-    h = ctx.lib.mggcn_spmm_plan_create_for(A.n(), A.m(), A.indptr.ctypes.data, A.indices.ctypes.data,
-                                           A.data.ctypes.data, max(int(max_d or 0), B.m()), B.m())
-    return spmm_buffer(ctx.lib, h)
+    return spmm_plan_for(ctx, A, max(int(max_d or 0), B.m()), B.m())
+
+
+def spmm_plan_for(ctx: context, A: csr_matrix, max_d: int, d_hint: int) -> spmm_buffer:
+    """One plan per (matrix, device, form): the layers of a model multiply by the same two matrices,
+    so the plan (0.9 GB and ~1 s of host work on the Reddit shape) is built once and shared.  The
+    form depends on the width only through narrow (<= 64: lanes per row) vs wide."""
+    form = ("narrow", (int(d_hint) + 15) // 16) if 1 <= int(d_hint) <= 64 else ("wide", 0)
+    knobs = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("MGGCN_SPMM_")))   # tuning / tests
+    key = (ctx.rank, form, knobs)
+    cache = A.__dict__.setdefault("_spmm_plans", {})
+    buf = cache.get(key)
+    if buf is None or buf.max_d < max_d:
+        ctx.set()
+        h = ctx.lib.mggcn_spmm_plan_create_for(A.n(), A.m(), A.indptr.ctypes.data, A.indices.ctypes.data,
+                                               A.data.ctypes.data, int(max_d), int(d_hint))
+        buf = cache[key] = spmm_buffer(ctx.lib, h)
+        buf.max_d = int(max_d)
+    return buf
 
 
 def matmul(ctx: context, A, B: dn_matrix, C: dn_matrix, *args, **kw) -> None:
