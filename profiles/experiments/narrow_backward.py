@@ -15,7 +15,7 @@ d = int(os.environ.get("EXP_D", "41"))
 B = pkg.dn_matrix.from_numpy(np.random.default_rng(0).standard_normal((n, d), dtype=np.float32))
 C = pkg.dn_matrix(n, d)
 for name, M in mats.items():
-    for lpe, panel in [(0, 8192), (0, 16384), (12, 8192), (12, 16384), (12, 32768), (16, 8192), (16, 16384), (16, 32768)]:
+    for lpe, panel in [(0, 4096), (0, 6144), (0, 8192), (0, 16384), (12, 8192), (12, 16384), (12, 32768), (16, 8192), (16, 16384), (16, 32768)]:
         if lpe: os.environ["MGGCN_SPMM_NARROW_LPE"] = str(lpe)
         else: os.environ.pop("MGGCN_SPMM_NARROW_LPE", None)
         os.environ["MGGCN_SPMM_PANEL_ROWS_NARROW"] = str(panel)
