@@ -228,3 +228,24 @@ def test_dist_oracle_matches_single(oracle):
     for r in range(P):
         for a, b in zip(D.ranks[r], S.layers):
             np.testing.assert_allclose(a.lin.W, b.lin.W, rtol=1e-4, atol=1e-6)
+
+
+def test_baseline_config0_cpu_spmm(oracle, pkg):
+    """BASELINE.json configs[0]: synthetic 10 k-node / 100 k-nnz CSR, SpMM at d = 128 on the CPU path
+    (the reference's 'test_matrix plumbing, no GPU' case): the oracle's SpMM on the exact generator
+    output, column-normalised as the trainer does, against SciPy in fp64; also beta = 1."""
+    import scipy.sparse as sp
+    n, d = 10_000, 128
+    ip, ix, dv = pkg.datasets.synth_uniform_csr(n, 10, seed=0)
+    A = oracle.Csr(ip, ix, dv.copy(), n)
+    oracle.normalize(A, True)
+    M = sp.csr_matrix((A.data.astype(np.float64), ix, ip), shape=(n, n))
+    np.testing.assert_allclose(np.asarray(M.sum(axis=0)).reshape(-1)[np.unique(ix)], 1.0, rtol=1e-5)   # column-stochastic
+    rng = np.random.default_rng(0)
+    B = rng.standard_normal((n, d)).astype(np.float32)
+    want = M @ B.astype(np.float64)
+    got = oracle.spmm(A, B)
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+    C0 = rng.standard_normal((n, d)).astype(np.float32)
+    got1 = oracle.spmm(A, B, C0.copy(), 1.0, 1.0)
+    assert np.abs(got1 - (want + C0)).max() <= 1e-4 * np.abs(want + C0).max()
