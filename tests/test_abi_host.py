@@ -256,3 +256,12 @@ def test_comm_library_exports_every_declared_symbol():
     assert nm is not None, "no nm tool"
     exported = set(re.findall(r"\b(mggcn_comm_[a-z0-9_]+)\b", nm))
     assert not [n for n in names if n not in exported], (names, sorted(exported))
+
+
+def test_public_headers_are_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/*.h must compile as C99 (no HIP / torch / C++ types)."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "mggcn.h"\n#include "mggcn_comm.h"\nint main(void) { return 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
