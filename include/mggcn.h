@@ -158,6 +158,16 @@ void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M,
 void mggcn_gemm_bias_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
                          uint32_t K, float alpha, const float *A, size_t lda, const float *B, size_t ldb,
                          const float *bias, float *C, size_t ldc, void *workspace, size_t workspace_bytes);
+/* C = (alpha * op(A) * op(B)) .* (Z > 0 ? 1 : slope)   (Z: M x N, ldz >= N; C is never read).
+ * Folds the NEXT leaky_relu_backward launch into the GEMM that produces its gradient operand: the reference
+ * runs G_out = G . W^T in layer i+1 (src/gcn.hpp:135-137) and then, in layer i, leaky_relu_backward(Z_i, G_out)
+ * (src/gcn.hpp:462-468, src/cuda_utils.cu:33-38) -- a pass that reads Z_i and G_out and writes T.  Z_i is layer
+ * i+1's own input X, so the mask is applied on the accumulator tile in this GEMM's epilogue: one read of Z, no
+ * extra pass, no extra write.  Same products and the same single multiply as the two launches -> bitwise equal. */
+void mggcn_gemm_lrelu_bwd_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
+                              uint32_t K, float alpha, const float *A, size_t lda, const float *B, size_t ldb,
+                              const float *Z, size_t ldz, float slope, float *C, size_t ldc, void *workspace,
+                              size_t workspace_bytes);
 
 /* ======================================================================== *
  * Element-wise / row kernels: one entry point per live launcher of
@@ -241,6 +251,22 @@ void mggcn_softmax_xent_fused_f32(mggcn_stream_t stream, float *H, const int32_t
 void mggcn_adam_fused_f32(mggcn_stream_t stream, float *param, float *grad, float *m, float *v,
                           float lr, float beta1, float beta2, float weight_decay, float c1, float c2,
                           float eps, size_t size);
+
+/* The same update for EVERY parameter tensor of a model in one launch (the reference runs seven launches per
+ * layer, src/gcn.hpp:146-172: 28 per epoch on the 4-layer Reddit model; this is 1).  `table_device`: n_tensors
+ * entries in DEVICE memory, built once (the pointers of a model never change); first_block = running sum of
+ * mggcn_adam_multi_blocks(size) over the preceding entries, total_blocks = the sum over all.  lr / beta / c1 /
+ * c2 / eps are shared (every layer takes the same step count); weight_decay is per tensor (0 for biases).
+ * Element-wise math identical to mggcn_adam_fused_f32 -> bitwise equal results. */
+typedef struct {
+    float *param, *grad, *m, *v;
+    uint64_t size;
+    float weight_decay;
+    uint32_t first_block;
+} mggcn_adam_tensor;
+uint32_t mggcn_adam_multi_blocks(uint64_t size);
+void mggcn_adam_multi_f32(mggcn_stream_t stream, const mggcn_adam_tensor *table_device, uint32_t n_tensors,
+                          uint32_t total_blocks, float lr, float beta1, float beta2, float c1, float c2, float eps);
 
 /* ======================================================================== *
  * Host-side graph preprocessing (multi-threaded CPU code, runs once per dataset;

@@ -15,6 +15,12 @@
  * issues the P per-communicator calls inside one ncclGroupStart/End.  Enqueue-only; fail-fast
  * (message + exit) like CHECK_NCCL (src/mg_gcn.hpp:60-68).  fp32 payloads only.
  *
+ * Two transports (picked at init, see mggcn_comm_transport): "rccl" -- one communicator per GPU,
+ * the reference's pattern; "p2p" -- event-ordered device-to-device copies pulled by every
+ * receiver on its own stream (hipMemcpyPeerAsync over xGMI, or same-device copies), sums formed in
+ * rank order on every GPU.  p2p is selected when two ranks share a GPU (RCCL refuses that: this is
+ * how the P > 1 schedules run on a one-GPU box) or with MGGCN_COMM_TRANSPORT=p2p.
+ *
  * Kept in its own library so that a process that already hosts an RCCL (e.g. PyTorch's
  * bundled one) never loads a second copy: the one-process-per-GPU host layer uses
  * torch.distributed instead and does not link this file.
@@ -36,6 +42,8 @@ typedef struct mggcn_comm mggcn_comm;
 mggcn_comm *mggcn_comm_init_all(int P, const int *devices);
 void mggcn_comm_destroy(mggcn_comm *comm);
 int mggcn_comm_size(const mggcn_comm *comm);
+/* "rccl" or "p2p" */
+const char *mggcn_comm_transport(const mggcn_comm *comm);
 
 /* recv[j] <- send_root (count floats) on every GPU j; send_root lives on GPU `root`. */
 void mggcn_comm_broadcast_f32(mggcn_comm *comm, const float *send_root, float *const *recv, size_t count,
@@ -43,6 +51,11 @@ void mggcn_comm_broadcast_f32(mggcn_comm *comm, const float *send_root, float *c
 /* recv[j][i*count .. (i+1)*count) <- send[i] for all i, on every GPU j. */
 void mggcn_comm_allgather_f32(mggcn_comm *comm, const float *const *send, float *const *recv, size_t count,
                               const mggcn_stream_t *streams);
+/* Variable-size exchange (the halo form of the shard exchange; the reference only
+ * analyses these volumes offline, test/data/prep.py:232-272): counts[j*P + k] floats go from GPU j to GPU k;
+ * send[j] holds rank j's outgoing pieces in destination order, recv[k] receives in source order. */
+void mggcn_comm_alltoallv_f32(mggcn_comm *comm, const float *const *send, float *const *recv,
+                              const size_t *counts, const mggcn_stream_t *streams);
 /* bufs[j] <- sum_i bufs[i], in place, on every GPU j. */
 void mggcn_comm_allreduce_sum_f32(mggcn_comm *comm, float *const *bufs, size_t count,
                                   const mggcn_stream_t *streams);

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int32, c_size_t, c_uint32, c_void_p
+from ctypes import c_float, c_int, c_int32, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmggcn_hip.so")
@@ -60,6 +60,8 @@ PROTOTYPES = {
                               c_size_t, c_float, vp, c_size_t, vp, c_size_t]),
     "mggcn_gemm_bias_f32": (None, [vp, c_int, c_int, c_uint32, c_uint32, c_uint32, c_float, vp, c_size_t, vp,
                                    c_size_t, vp, vp, c_size_t, vp, c_size_t]),
+    "mggcn_gemm_lrelu_bwd_f32": (None, [vp, c_int, c_int, c_uint32, c_uint32, c_uint32, c_float, vp, c_size_t, vp,
+                                        c_size_t, vp, c_size_t, c_float, vp, c_size_t, vp, c_size_t]),
     "mggcn_leaky_relu_forward_f32": (None, [vp, vp, vp, c_size_t, c_float]),
     "mggcn_leaky_relu_backward_f32": (None, [vp, vp, vp, vp, c_size_t, c_float]),
     "mggcn_broadcast_rows_f32": (None, [vp, vp, vp, c_size_t, c_size_t, c_int]),
@@ -80,6 +82,8 @@ PROTOTYPES = {
     "mggcn_softmax_xent_fused_f32": (None, [vp, vp, vp, c_size_t, c_size_t, c_float, vp]),
     "mggcn_adam_fused_f32": (None, [vp, vp, vp, vp, vp, c_float, c_float, c_float, c_float, c_float,
                                     c_float, c_float, c_size_t]),
+    "mggcn_adam_multi_blocks": (c_uint32, [c_uint64]),
+    "mggcn_adam_multi_f32": (None, [vp, vp, c_uint32, c_uint32, c_float, c_float, c_float, c_float, c_float, c_float]),
     "mggcn_csr_normalize_host": (None, [c_uint32, c_uint32, vp, vp, vp, c_int]),
     "mggcn_csr_transpose_host": (None, [c_uint32, c_uint32, vp, vp, vp, vp, vp, vp]),
     "mggcn_csr_block_split_count_host": (None, [vp, vp, c_uint32, c_uint32, vp, c_uint32, vp]),

@@ -330,6 +330,31 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float *__restrict__ p, 
     }
 }
 
+// one launch for EVERY parameter tensor of the model: block b works on 1024 elements of the tensor whose
+// [first_block, first_block + blocks) range holds b (a model has ~8 tensors: linear search)
+__device__ __forceinline__ void adam_one(float *p, float *g, float *m, float *v, size_t i, float step, float b1,
+                                         float b2, float wd, float c2, float eps) {
+    const float pi = p[i];
+    const float gi = fmaf(wd, pi, g[i]);
+    const float mi = (1.f - b1) * gi + b1 * m[i];
+    const float vi = (1.f - b2) * gi * gi + b2 * v[i];
+    g[i] = gi; m[i] = mi; v[i] = vi;
+    p[i] = pi - step * mi / (sqrtf(vi / c2) + eps);
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const mggcn_adam_tensor *__restrict__ table, uint32_t n_tensors,
+                                                         float step, float b1, float b2, float c2, float eps) {
+    uint32_t t = 0;
+    while (t + 1 < n_tensors && table[t + 1].first_block <= blockIdx.x) t++;
+    const mggcn_adam_tensor T = table[t];
+    const size_t base = (size_t)(blockIdx.x - T.first_block) * 1024;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t i = base + (size_t)k * 256 + threadIdx.x;
+        if (i < T.size) adam_one(T.param, T.grad, T.m, T.v, i, step, b1, b2, T.weight_decay, c2, eps);
+    }
+}
+
 }  // namespace
 
 // ============================ C ABI =========================================
@@ -502,6 +527,18 @@ MGGCN_API void mggcn_softmax_xent_fused_f32(mggcn_stream_t stream, float *H, con
     else if (m <= 512) MGGCN_XENT(8);
     else MGGCN_XENT(16);
 #undef MGGCN_XENT
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API uint32_t mggcn_adam_multi_blocks(uint64_t size) { return (uint32_t)((size + 1023) / 1024); }
+
+MGGCN_API void mggcn_adam_multi_f32(mggcn_stream_t stream, const mggcn_adam_tensor *table_device, uint32_t n_tensors,
+                                    uint32_t total_blocks, float lr, float beta1, float beta2, float c1, float c2,
+                                    float eps) {
+    if (!n_tensors || !total_blocks) return;
+    MGGCN_REQUIRE(table_device != nullptr, "mggcn_adam_multi_f32 needs the tensor table");
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(total_blocks), dim3(256), 0, as_stream(stream), table_device, n_tensors,
+                       lr / c1, beta1, beta2, c2, eps);
     MGGCN_CHECK_LAUNCH();
 }
 

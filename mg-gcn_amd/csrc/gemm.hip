@@ -37,6 +37,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128;
 constexpr int BK = 32;
 
+// what happens to alpha * (A B) on its way to C besides beta * C
+struct Epilogue {
+    const float *bias = nullptr;     // + 1 bias^T            (mggcn_gemm_bias_f32)
+    const float *mask = nullptr;     // .* (Z > 0 ? 1 : slope) (mggcn_gemm_lrelu_bwd_f32)
+    size_t ldz = 0;
+    float slope = 0.f;
+};
+
+__device__ __forceinline__ float epilogue_value(const Epilogue &e, float av, float beta, const float *cp, size_t row, size_t col) {
+    // bias: the row vector the reference broadcasts into C before its beta = 1 sgemm (src/gcn.hpp:116-123);
+    // same single rounding as fmaf(1, bias, alpha*v)
+    if (e.bias) return fmaf(1.f, e.bias[col], av);
+    // mask: leaky_relu_backward of the consumer (src/cuda_utils.cu:33-38) on the value a beta = 0 GEMM would store
+    if (e.mask) return e.mask[row * e.ldz + col] > 0.f ? av : e.slope * av;
+    return beta == 0.f ? av : fmaf(beta, *cp, av);
+}
+
 // Loads 4 consecutive elements along the contiguous dimension, zero-filled
 // outside [0, limit).  vec: the whole operand is 16-byte aligned with ld % 4 == 0.
 __device__ __forceinline__ float4 load4_guard(const float *__restrict__ p, long long first,
@@ -105,7 +122,7 @@ template <bool A_KCONTIG, bool B_KCONTIG, int BN>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(
     uint32_t M, uint32_t N, uint32_t K, float alpha, const float *__restrict__ A, size_t lda,
     const float *__restrict__ B, size_t ldb, float beta, float *__restrict__ C, size_t ldc,
-    float *__restrict__ slab, uint32_t k_chunk, bool a_vec, bool b_vec, const float *__restrict__ bias) {
+    float *__restrict__ slab, uint32_t k_chunk, bool a_vec, bool b_vec, const Epilogue epi) {
     constexpr int WN = BN == 128 ? 2 : 1;           // waves along N
     constexpr int WM = 4 / WN;                      // waves along M
     constexpr int MI = BM / WM / 32;                // MFMA blocks per wave along M (2 or 1)
@@ -178,10 +195,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(
                         slab[((size_t)blockIdx.z * M + row) * N + col] = v;
                     } else {
                         float *cp = C + (size_t)row * ldc + col;
-                        // bias: the row vector the reference broadcasts into C before its beta = 1 sgemm
-                        // (src/gcn.hpp:116-123); same single rounding as fmaf(1, bias, alpha*v)
-                        if (bias) *cp = fmaf(1.f, bias[col], alpha * v);
-                        else *cp = beta == 0.f ? alpha * v : fmaf(beta, *cp, alpha * v);
+                        *cp = epilogue_value(epi, alpha * v, beta, cp, (size_t)row, (size_t)col);
                     }
                 }
             }
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float *__
                                                                  uint32_t splits, uint32_t M, uint32_t N,
                                                                  float alpha, float beta,
                                                                  float *__restrict__ C, size_t ldc,
-                                                                 const float *__restrict__ bias) {
+                                                                 const Epilogue epi) {
     __shared__ float part[8][33];
     const uint32_t total = M * N;                    // < 2^32: checked by the launcher
     const uint32_t lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -213,8 +227,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float *__
 #pragma unroll
             for (int g = 1; g < 8; g++) t += part[g][lane];
             float *cp = C + (size_t)(i / N) * ldc + (i % N);
-            if (bias) *cp = fmaf(1.f, bias[i % N], alpha * t);
-            else *cp = beta == 0.f ? alpha * t : fmaf(beta, *cp, alpha * t);
+            *cp = epilogue_value(epi, alpha * t, beta, cp, (size_t)(i / N), (size_t)(i % N));
         }
         __syncthreads();
     }
@@ -325,7 +338,7 @@ MGGCN_API size_t mggcn_gemm_workspace_bytes(int trans_a, int trans_b, uint32_t M
 namespace {
 void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N, uint32_t K, float alpha,
                    const float *A, size_t lda, const float *B, size_t ldb, float beta, float *C, size_t ldc,
-                   void *workspace, size_t workspace_bytes, const float *bias);
+                   void *workspace, size_t workspace_bytes, const Epilogue &epi);
 }
 
 MGGCN_API void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
@@ -333,7 +346,7 @@ MGGCN_API void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, u
                               size_t ldb, float beta, float *C, size_t ldc, void *workspace,
                               size_t workspace_bytes) {
     gemm_dispatch(stream, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, workspace, workspace_bytes,
-                  nullptr);
+                  Epilogue{});
 }
 
 MGGCN_API void mggcn_gemm_bias_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
@@ -346,14 +359,28 @@ MGGCN_API void mggcn_gemm_bias_f32(mggcn_stream_t stream, int trans_a, int trans
         mggcn_broadcast_rows_f32(stream, bias, C, (size_t)M * N, N, 1);
         return;
     }
-    gemm_dispatch(stream, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, workspace, workspace_bytes,
-                  bias);
+    Epilogue e;
+    e.bias = bias;
+    gemm_dispatch(stream, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, workspace, workspace_bytes, e);
+}
+
+MGGCN_API void mggcn_gemm_lrelu_bwd_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
+                                        uint32_t K, float alpha, const float *A, size_t lda, const float *B,
+                                        size_t ldb, const float *Z, size_t ldz, float slope, float *C, size_t ldc,
+                                        void *workspace, size_t workspace_bytes) {
+    MGGCN_REQUIRE(Z != nullptr && ldz >= N, "mggcn_gemm_lrelu_bwd_f32 needs the activation matrix Z (ldz >= N)");
+    MGGCN_REQUIRE(K > 0 || !M || !N, "mggcn_gemm_lrelu_bwd_f32: K == 0");
+    Epilogue e;
+    e.mask = Z;
+    e.ldz = ldz;
+    e.slope = slope;
+    gemm_dispatch(stream, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, workspace, workspace_bytes, e);
 }
 
 namespace {
 void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N, uint32_t K, float alpha,
                    const float *A, size_t lda, const float *B, size_t ldb, float beta, float *C, size_t ldc,
-                   void *workspace, size_t workspace_bytes, const float *bias) {
+                   void *workspace, size_t workspace_bytes, const Epilogue &epi) {
     if (!M || !N) return;
     hipStream_t st = as_stream(stream);
     MGGCN_REQUIRE(C != nullptr && ldc >= N, "bad C / ldc");
@@ -376,7 +403,7 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
                            lda, B, ldb, slab, sp.k_chunk, M);
         MGGCN_CHECK_LAUNCH();
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(std::min<unsigned>((M * N + 31) / 32, 2048u)), dim3(256), 0,
-                           st, slab, sp.splits, M, N, alpha, beta, C, ldc, bias);
+                           st, slab, sp.splits, M, N, alpha, beta, C, ldc, epi);
         MGGCN_CHECK_LAUNCH();
         return;
     }
@@ -395,7 +422,7 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
 
 #define MGGCN_GEMM_LAUNCH(AK, BKC, BNV)                                                               \
     hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKC, BNV>), grid, block, 0, st, M, N, K, alpha, A, lda, B, ldb, \
-                       beta, C, ldc, slab, sp.k_chunk, a_vec, b_vec, bias)
+                       beta, C, ldc, slab, sp.k_chunk, a_vec, b_vec, epi)
     if (bn == 128) {
         if (a_kc && b_kc) MGGCN_GEMM_LAUNCH(true, true, 128);
         else if (a_kc) MGGCN_GEMM_LAUNCH(true, false, 128);
@@ -411,7 +438,7 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
     MGGCN_CHECK_LAUNCH();
     if (sp.splits > 1) {
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(std::min<unsigned>((M * N + 31) / 32, 2048u)), dim3(256), 0,
-                           st, slab, sp.splits, M, N, alpha, beta, C, ldc, bias);
+                           st, slab, sp.splits, M, N, alpha, beta, C, ldc, epi);
         MGGCN_CHECK_LAUNCH();
     }
 }

@@ -42,7 +42,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib, ops
-from .gcn import MGGCN_SPMM_LEAKY_RELU, _SQRT_1_3, softmax_cross_entropy_loss
+from .gcn import MGGCN_SPMM_LEAKY_RELU, _SQRT_1_3, adam_update_all, link_fused_backward, softmax_cross_entropy_loss
 from .matrix import context, csr_matrix, dn_matrix
 
 
@@ -476,7 +476,7 @@ class dist_sparse_linear:
         rows = B.local.n()
         cs = dctx.bcast_stream_id()
         ctx.record(name + "0_matmul-spmm", 0)
-        ctx.wait(name + "0_matmul-spmm", 1)                    # comm stream sees the producer of B
+        ctx.wait(name + "0_matmul-spmm", cs)                   # comm stream sees the producer of B
         if self.mode == "allgather":
             # the exchange, cut into K pieces of the shard (rows cb[c]..cb[c+1] of every rank): all K
             # all-gathers are queued on the comm stream at once and land one after the other
@@ -560,6 +560,7 @@ class dist_row_linear:
         if off_b != in_ * out:
             self.G_flat.zero_()                                # the padding takes part in the sum
         self._grad_pending = None
+        self._dctx = dctx
         self.backward_out, self.fused = backward_out, fused
         self.W.init(dctx)
         self.b.init(dctx, _SQRT_1_3)
@@ -585,7 +586,7 @@ class dist_row_linear:
         self.X = X
 
     def backward(self, dctx: dist_context, G: dist_row_dn_matrix, G_out: Optional[dist_row_dn_matrix],
-                 discard: bool = True) -> None:
+                 discard: bool = True, mask: Optional[dist_row_dn_matrix] = None) -> None:
         ctx, n = dctx.ctx, self.name
         if self.ones is None or self.ones.m() != G.local.n():
             self.ones = dn_matrix(1, G.local.n(), device=ctx.device)
@@ -597,7 +598,9 @@ class dist_row_linear:
         # finish_backward() (end of dist_gcn.backward) / adam_update
         self._grad_pending = dctx.all_reduce_sum_async(self.G_flat, 0)
         ctx.record(n + "1_2_matmul-gemm", 0)
-        if self.backward_out:
+        if self.backward_out and mask is not None:             # leaky_relu' of the layer below in the epilogue
+            ops.matmul_lrelu_backward(ctx, G.local, self.W.local, mask.local, G_out.local, 1.0, False, True)
+        elif self.backward_out:
             ops.matmul(ctx, G.local, self.W.local, G_out.local, 1.0, 0.0 if discard else 1.0, False, True)
         ctx.record(n + "1_3_matmul-gemm", 0)
         ctx.register_timer(n + "1_matmul-gemm", n + "1_0_matmul-gemm", n + "1_3_matmul-gemm")
@@ -607,15 +610,23 @@ class dist_row_linear:
             self._grad_pending.wait(0)
             self._grad_pending = None
 
+    def adam_state(self, ctx: context) -> None:
+        if self.mW is None:
+            d = self._dctx
+            self.mW, self.vW = repl_dn_matrix(d, self.W.shape()), repl_dn_matrix(d, self.W.shape())
+            self.mb, self.vb = repl_dn_matrix(d, self.b.shape()), repl_dn_matrix(d, self.b.shape())
+            for t in (self.mW, self.vW, self.mb, self.vb):
+                t.zero(d)
+            self.step = 0
+
+    def adam_tensors(self, weight_decay: float):
+        return [(self.W.local, self.G_W.local, self.mW.local, self.vW.local, weight_decay),
+                (self.b.local, self.G_b.local, self.mb.local, self.vb.local, 0.0)]
+
     def adam_update(self, dctx: dist_context, lr, beta1, beta2, weight_decay, eps) -> None:
         ctx = dctx.ctx
         self.finish_backward(dctx)
-        if self.mW is None:
-            self.mW, self.vW = repl_dn_matrix(dctx, self.W.shape()), repl_dn_matrix(dctx, self.W.shape())
-            self.mb, self.vb = repl_dn_matrix(dctx, self.b.shape()), repl_dn_matrix(dctx, self.b.shape())
-            for t in (self.mW, self.vW, self.mb, self.vb):
-                t.zero(dctx)
-            self.step = 0
+        self.adam_state(ctx)
         self.step += 1
         bc1 = float(np.float32(1 - beta1 ** self.step))
         bc2 = float(np.float32(1 - beta2 ** self.step))
@@ -650,12 +661,12 @@ class dist_gcn_layer:
                  HW_buffer=None, bcast_buffer=None, bcast_buffer2=None, fused: bool = False,
                  mode: str = "allgather"):
         torch = _torch()
-        if residual_layer:
-            raise NotImplementedError("residual_layer is never enabled by the reference CLI")
         P, dev = dctx.P, dctx.ctx.device
         self.name = name
         self.A = dist_sparse_linear(name, A, A_T, bcast_buffer, bcast_buffer2, mode)
         self.lin = dist_row_linear(dctx, name, in_, out, backward_spmm, fused)
+        self.residual_layer = bool(residual_layer)            # gcn.hpp:527-553
+        self.res_lin = dist_row_linear(dctx, name, in_, out, backward_spmm, False) if residual_layer and in_ != out else None
         mn = min(in_, out)
         self.AHW_buffer = torch.empty(max(A.n() * out, A_T.n() * in_) // P, dtype=torch.float32, device=dev)
         self.HW = dist_row_dn_matrix(dctx, A.m(), mn, HW_buffer)
@@ -664,6 +675,10 @@ class dist_gcn_layer:
         self.G_out = dist_row_dn_matrix(dctx, A_T.n(), in_, self.AHW_buffer)
         self.activation, self.backward_spmm, self.fused = activation, backward_spmm, fused
         self.H = None
+        self.mask_input_grad = self.grad_premasked = False      # see gcn.link_fused_backward
+
+    def gemm_first(self) -> bool:
+        return self.HW.m() == self.AHW.m()
 
     def __call__(self, dctx: dist_context, H: dist_row_dn_matrix) -> dist_row_dn_matrix:
         ctx, n = dctx.ctx, self.name
@@ -684,12 +699,16 @@ class dist_gcn_layer:
             ops.leaky_relu_forward(ctx, self.AHW.local, self.AHW.local)
             ctx.record(n + "0_1_activation", 0)
             ctx.register_timer(n + "0_activation", n + "0_0_activation", n + "0_1_activation")
+        if self.res_lin is not None:
+            self.res_lin(dctx, H, self.AHW, False)
+        elif self.residual_layer:
+            ops.axpy(ctx, H.local, self.AHW.local, 1.0)
         return self.AHW
 
     def backward(self, dctx: dist_context, G: dist_row_dn_matrix) -> dist_row_dn_matrix:
         ctx, n = dctx.ctx, self.name
         T = G
-        if self.activation:
+        if self.activation and not self.grad_premasked:
             ctx.record(n + "1_0_activation", 0)
             ops.leaky_relu_backward(ctx, self.AHW.local, G.local, self.AHW.local)
             ctx.record(n + "1_1_activation", 0)
@@ -701,20 +720,31 @@ class dist_gcn_layer:
                 self.A.backward(dctx, T, G_HW)
             else:
                 G_HW = T
-            self.lin.backward(dctx, G_HW, self.G_out)
-            return self.G_out
-        self.lin.setX(self.H)
-        self.lin.backward(dctx, T, self.G_HW)
-        if self.backward_spmm:
-            self.A.backward(dctx, self.G_HW, self.G_out)
-            return self.G_out
-        return self.G_HW
+            self.lin.backward(dctx, G_HW, self.G_out, mask=self.H if self.mask_input_grad else None)
+            G_out = self.G_out
+        else:
+            self.lin.setX(self.H)
+            self.lin.backward(dctx, T, self.G_HW)
+            G_out = self.G_HW
+            if self.backward_spmm:
+                self.A.backward(dctx, self.G_HW, self.G_out)
+                G_out = self.G_out
+        if self.res_lin is not None:
+            self.res_lin.backward(dctx, G, G_out, False)
+        elif self.residual_layer:
+            ops.axpy(ctx, G.local, G_out.local, 1.0)
+        return G_out
+
+    def linears(self):
+        return [self.lin] + ([self.res_lin] if self.res_lin is not None else [])
 
     def finish_backward(self, dctx) -> None:
-        self.lin.finish_backward(dctx)
+        for lin in self.linears():
+            lin.finish_backward(dctx)
 
     def adam_update(self, dctx, lr, beta1, beta2, weight_decay, eps):
-        self.lin.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
+        for lin in self.linears():
+            lin.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
 
     def b(self): return self.lin.get_b()
     def W(self): return self.lin.get_W()
@@ -787,6 +817,8 @@ class dist_gcn:
             self.layers_.append(dist_gcn_layer(dctx, f"{i - 1}_", A_T, A, sizes[i - 1], sizes[i],
                                                i + 1 < len(sizes), residual_layer, i != 1, self.HW_buffer,
                                                self.bcast_buffer, self.bcast_buffer2, fused, mode))
+        link_fused_backward(self.layers_, fused)
+        self.fused, self._adam = fused, None
 
     def __call__(self, dctx, H):
         for layer in self.layers_:
@@ -805,8 +837,14 @@ class dist_gcn:
             layer.finish_backward(dctx)
 
     def adam_update(self, dctx, lr, beta1, beta2, weight_decay, eps) -> None:
+        if not self.fused:
+            for layer in self.layers_:
+                layer.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
+            return
         for layer in self.layers_:
-            layer.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
+            layer.finish_backward(dctx)
+        self._adam = adam_update_all(dctx.ctx, [lin for l in self.layers_ for lin in l.linears()], self._adam, lr,
+                                     beta1, beta2, weight_decay, eps)
 
     def train_step(self, dctx: dist_context, H: dist_row_dn_matrix, Y: dist_row_dn_matrix, lr, beta1, beta2,
                    weight_decay, eps):

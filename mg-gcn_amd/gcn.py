@@ -9,7 +9,9 @@ adam_update members, buffer aliasing and timer names.
 kernels -- identical math, fewer passes:
   * leaky-ReLU folded into the SpMM epilogue when the SpMM is the layer's last op,
   * softmax + argmax + log-prob + gradient in one kernel instead of 8 + a GEMM,
-  * one Adam kernel per tensor instead of 4.
+  * leaky-ReLU-backward folded into the epilogue of the GEMM that PRODUCES its gradient operand
+    (layer i+1's G_out = G_HW . W^T, masked by layer i+1's own input = layer i's activated output),
+  * one Adam launch for all parameter tensors of the model instead of 7 per layer.
 ``fused=False`` runs the reference's launch sequence one for one.
 """
 from __future__ import annotations
@@ -97,7 +99,10 @@ class linear:
         ctx.register_timer(n + "0_matmul-gemm", n + "0_0_matmul-gemm", n + "0_1_matmul-gemm")
         self.X = X
 
-    def backward(self, ctx: context, G: dn_matrix, G_out: Optional[dn_matrix], discard: bool = True) -> None:
+    def backward(self, ctx: context, G: dn_matrix, G_out: Optional[dn_matrix], discard: bool = True,
+                 mask: Optional[dn_matrix] = None) -> None:
+        """``mask`` (fused path): the activated output Z of the layer below -- G_out leaves the GEMM already
+        multiplied by leaky_relu'(Z), i.e. it IS the T of that layer's backward (gcn.hpp:462-468)."""
         n = self.name
         if self.ones is None or self.ones.m() != G.n():
             self.ones = dn_matrix(1, G.n())
@@ -107,7 +112,10 @@ class linear:
         ctx.record(n + "1_1_matmul-gemm", 0)
         ops.matmul(ctx, self.X, G, self.G_W, 1.0, 0.0, True)
         ctx.record(n + "1_2_matmul-gemm", 0)
-        if self.backward_out:
+        if self.backward_out and mask is not None:
+            assert discard
+            ops.matmul_lrelu_backward(ctx, G, self.W, mask, G_out, 1.0, False, True)
+        elif self.backward_out:
             ops.matmul(ctx, G, self.W, G_out, 1.0, 0.0 if discard else 1.0, False, True)
         ctx.record(n + "1_3_matmul-gemm", 0)
         ctx.register_timer(n + "1_matmul-gemm", n + "1_0_matmul-gemm", n + "1_3_matmul-gemm")
@@ -116,14 +124,21 @@ class linear:
         ops.axpby(ctx, self.G_W, self.W, -lr, 1 - weight_decay)
         ops.axpy(ctx, self.G_b, self.b, -lr)
 
-    def adam_update(self, ctx: context, lr: float, beta1: float, beta2: float, weight_decay: float,
-                    eps: float) -> None:
+    def adam_state(self, ctx: context) -> None:
         if self.mW is None:
             self.mW, self.vW = dn_matrix(self.W.shape()), dn_matrix(self.W.shape())
             self.mb, self.vb = dn_matrix(self.b.shape()), dn_matrix(self.b.shape())
             for t in (self.mW, self.vW, self.mb, self.vb):
                 t.zero(ctx)
             self.step = 0
+
+    def adam_tensors(self, weight_decay: float):
+        """(param, grad, m, v, weight decay) of this layer for ops.adam_table: W decays, b does not (gcn.hpp:163)"""
+        return [(self.W, self.G_W, self.mW, self.vW, weight_decay), (self.b, self.G_b, self.mb, self.vb, 0.0)]
+
+    def adam_update(self, ctx: context, lr: float, beta1: float, beta2: float, weight_decay: float,
+                    eps: float) -> None:
+        self.adam_state(ctx)
         self.step += 1
         bc1 = float(np.float32(1 - beta1 ** self.step))
         bc2 = float(np.float32(1 - beta2 ** self.step))
@@ -156,11 +171,12 @@ class gcn_layer:
     def __init__(self, name: str, A: csr_matrix, A_T: csr_matrix, in_: int, out: int, activation: bool,
                  residual_layer: bool = False, backward_spmm: bool = True, HW_buffer=None, fused: bool = False):
         torch = _torch()
-        if residual_layer:
-            raise NotImplementedError("residual_layer is never enabled by the reference CLI (SURVEY.md 8(f) rank 4)")
         self.name = name
         self.A = sparse_linear(name, A, A_T)
         self.lin = linear(name, in_, out, backward_spmm, fused)
+        # residual connection (gcn.hpp:418, :430): a second linear when the widths differ, a plain add otherwise
+        self.residual_layer = bool(residual_layer)
+        self.res_lin = linear(name, in_, out, backward_spmm, False) if residual_layer and in_ != out else None
         mn = min(in_, out)
         if HW_buffer is None:
             HW_buffer = torch.empty(max(A.m(), A_T.n()) * mn, dtype=torch.float32, device="cuda")
@@ -171,6 +187,12 @@ class gcn_layer:
         self.G_out = dn_matrix(A_T.n(), in_, self.AHW_buffer)
         self.activation, self.backward_spmm, self.fused = activation, backward_spmm, fused
         self.H: Optional[dn_matrix] = None
+        # fused backward (set by the model): mask_input_grad -- my G_out GEMM applies leaky_relu'(H) of the layer
+        # below; grad_premasked -- the G I receive already carries my own activation's mask
+        self.mask_input_grad = self.grad_premasked = False
+
+    def gemm_first(self) -> bool:
+        return self.HW.m() == self.AHW.m()        # out <= in (gcn.hpp:439)
 
     def __call__(self, ctx: context, H: dn_matrix) -> dn_matrix:
         self.H = H
@@ -191,12 +213,16 @@ class gcn_layer:
             ops.leaky_relu_forward(ctx, self.AHW, self.AHW)
             ctx.record(n + "0_1_activation", 0)
             ctx.register_timer(n + "0_activation", n + "0_0_activation", n + "0_1_activation")
+        if self.res_lin is not None:              # gcn.hpp:453-456: AHW += H . W_res + 1 b_res^T
+            self.res_lin(ctx, H, self.AHW, False)
+        elif self.residual_layer:
+            ops.axpy(ctx, H, self.AHW, 1.0)
         return self.AHW
 
     def backward(self, ctx: context, G: dn_matrix) -> dn_matrix:
         n = self.name
         T = G
-        if self.activation:
+        if self.activation and not self.grad_premasked:
             ctx.record(n + "1_0_activation", 0)
             ops.leaky_relu_backward(ctx, self.AHW, G, self.AHW)
             ctx.record(n + "1_1_activation", 0)
@@ -208,19 +234,31 @@ class gcn_layer:
                 self.A.backward(ctx, T, G_HW)
             else:
                 G_HW = T
-            self.lin.backward(ctx, G_HW, self.G_out)
-            return self.G_out
-        self.lin.setX(self.H)
-        self.lin.backward(ctx, T, self.G_HW)
-        if self.backward_spmm:
-            self.A.backward(ctx, self.G_HW, self.G_out)
-            return self.G_out
-        return self.G_HW
+            self.lin.backward(ctx, G_HW, self.G_out, mask=self.H if self.mask_input_grad else None)
+            G_out = self.G_out
+        else:
+            self.lin.setX(self.H)
+            self.lin.backward(ctx, T, self.G_HW)
+            G_out = self.G_HW
+            if self.backward_spmm:
+                self.A.backward(ctx, self.G_HW, self.G_out)
+                G_out = self.G_out
+        if self.res_lin is not None:              # gcn.hpp:484-487: the residual branch sees the incoming G
+            self.res_lin.backward(ctx, G, G_out, False)
+        elif self.residual_layer:
+            ops.axpy(ctx, G, G_out, 1.0)
+        return G_out
 
-    def update(self, ctx, lr, weight_decay): self.lin.update(ctx, lr, weight_decay)
+    def linears(self):
+        return [self.lin] + ([self.res_lin] if self.res_lin is not None else [])
+
+    def update(self, ctx, lr, weight_decay):
+        for lin in self.linears():
+            lin.update(ctx, lr, weight_decay)
 
     def adam_update(self, ctx, lr, beta1, beta2, weight_decay, eps):
-        self.lin.adam_update(ctx, lr, beta1, beta2, weight_decay, eps)
+        for lin in self.linears():
+            lin.adam_update(ctx, lr, beta1, beta2, weight_decay, eps)
 
     def b(self): return self.lin.get_b()
     def W(self): return self.lin.get_W()
@@ -321,6 +359,36 @@ class softmax_cross_entropy_loss:
         return self.G
 
 
+def link_fused_backward(layers, fused: bool) -> None:
+    """fused backward: layer i+1's G_out GEMM applies layer i's leaky_relu' -- possible when layer i+1 is
+    GEMM-first (its G_out comes out of a GEMM, gcn.hpp:479-481) and propagates a gradient at all"""
+    for lo, hi in zip(layers[:-1], layers[1:]):
+        ok = bool(fused) and lo.activation and hi.gemm_first() and hi.lin.backward_out
+        # a residual branch needs the UNMASKED incoming gradient (gcn.hpp:484-487) and adds to G_out afterwards
+        ok = ok and not getattr(lo, "residual_layer", False) and not getattr(hi, "residual_layer", False)
+        hi.mask_input_grad = lo.grad_premasked = ok
+
+
+def adam_update_all(ctx: context, lins, state, lr: float, beta1: float, beta2: float, weight_decay: float, eps: float):
+    """ONE launch for every parameter tensor of the model (linear::adam_update of every layer, gcn.hpp:146-172
+    and :990-994).  ``state`` = (weight_decay, ops.adam_table) from the previous call or None."""
+    for lin in lins:
+        lin.adam_state(ctx)
+        lin.step += 1
+    if state is None or state[0] != weight_decay:
+        tensors = [t for lin in lins for t in lin.adam_tensors(weight_decay)]
+        state = (weight_decay, ops.adam_table(ctx, tensors))
+    step = lins[0].step
+    assert all(lin.step == step for lin in lins)
+    bc1 = float(np.float32(1 - beta1 ** step))
+    bc2 = float(np.float32(1 - beta2 ** step))
+    ctx.record("0_adam-update", 0)
+    state[1].step(ctx, lr, beta1, beta2, bc1, bc2, eps)
+    ctx.record("1_adam-update", 0)
+    ctx.register_timer("adam-update", "0_adam-update", "1_adam-update")
+    return state
+
+
 class gcn:
     """reference src/gcn.hpp:937-995.  The constructor column-normalises A, builds
     A_T and hands (A_T, A) to the layers -- forward multiplies by A_T (:946-955)."""
@@ -339,6 +407,8 @@ class gcn:
         for i in range(1, len(sizes)):
             self.layers_.append(gcn_layer(f"{i - 1}_", A_T, A, sizes[i - 1], sizes[i], i + 1 < len(sizes),
                                           residual_layer, i != 1, self.HW_buffer, fused))
+        link_fused_backward(self.layers_, fused)
+        self._adam = None
         if weights is not None:                     # test constructor, gcn.hpp:957-963
             assert len(weights) == len(self.layers_)
             for layer, (W, b) in zip(self.layers_, weights):
@@ -378,8 +448,12 @@ class gcn:
 
     def adam_update(self, ctx: context, lr: float, beta1: float, beta2: float, weight_decay: float,
                     eps: float) -> None:
-        for layer in self.layers_:
-            layer.adam_update(ctx, lr, beta1, beta2, weight_decay, eps)
+        if not self.fused:
+            for layer in self.layers_:
+                layer.adam_update(ctx, lr, beta1, beta2, weight_decay, eps)
+            return
+        self._adam = adam_update_all(ctx, [lin for l in self.layers_ for lin in l.linears()], self._adam, lr, beta1,
+                                     beta2, weight_decay, eps)
 
     def layers(self) -> List[gcn_layer]:
         return self.layers_

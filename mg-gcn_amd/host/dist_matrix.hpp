@@ -3,12 +3,14 @@
 // Same names as the reference's src/dist_matrix.hpp: dist_context (:12-90),
 // dist_row_csr_matrix (:170-260), dist_row_dn_matrix (:394-532), repl_dn_matrix (:534-639).
 // One host thread drives P GPUs through per-GPU contexts; collectives go through
-// libmggcn_comm.so (RCCL, include/mggcn_comm.h).  The column-partition classes
-// (dist_csr_matrix, dist_dn_matrix) are dead code in the reference (only reachable from a
-// commented-out branch of main.cpp) and are not rebuilt.
+// libmggcn_comm.so (include/mggcn_comm.h: RCCL, or event-ordered peer copies when ranks share
+// a GPU).  The column-partition classes (dist_csr_matrix, dist_dn_matrix) are dead code in the
+// reference (only reachable from a commented-out branch of main.cpp) and are not rebuilt.
 #pragma once
 
+#include <algorithm>
 #include <cassert>
+#include <cstdlib>
 #include <numeric>
 #include <ostream>
 #include <vector>
@@ -26,15 +28,25 @@ public:
     int bcast_stream_id() const { return overlap ? 1 : 0; }     // reference :20-22
 
     dist_context() = default;
+    // Rank i drives GPU i (reference :26-31).  MGGCN_OVERSUBSCRIBE=1 wraps the ranks over the GPUs that
+    // are visible (rank i -> GPU i mod count): the whole P-rank schedule on fewer GPUs, with the
+    // communication library's peer-copy transport -- a rehearsal / debugging aid, not a fast path.
     dist_context(std::size_t P, bool overlap = true) : overlap(overlap) {
-        for (std::size_t i = 0; i < P; i++) contexts.emplace_back(i);
-        comm_ = std::shared_ptr<mggcn_comm>(mggcn_comm_init_all((int)P, nullptr), &mggcn_comm_destroy);
+        const int count = mggcn_device_count();
+        const char *os = std::getenv("MGGCN_OVERSUBSCRIBE");
+        const bool wrap = os && std::atoi(os) != 0;
+        if ((int)P > count && !wrap) throw matrix_error("dist_context: fewer GPUs visible than ranks");
+        std::vector<int> devices;
+        for (std::size_t i = 0; i < P; i++) devices.push_back((int)(i % (std::size_t)std::max(count, 1)));
+        for (std::size_t i = 0; i < P; i++) contexts.emplace_back((std::size_t)devices[i]);
+        comm_ = std::shared_ptr<mggcn_comm>(mggcn_comm_init_all((int)P, devices.data()), &mggcn_comm_destroy);
     }
 
     auto size() const { return contexts.size(); }
     void sync() const { for (const auto &c : contexts) c.sync(); }
     const context &operator[](std::size_t i) const { return contexts[i]; }
     mggcn_comm *comm() const { return comm_.get(); }
+    std::string transport() const { return mggcn_comm_transport(comm_.get()); }
 
     std::vector<mggcn_stream_t> streams(std::size_t stream_id) const {
         std::vector<mggcn_stream_t> s;
@@ -58,17 +70,31 @@ public:
     }
 };
 
+// pieces the exchange of one SpMM is cut into (all-gather schedule): with K pieces the SpMM over
+// piece c runs while piece c+1 is on the wire.  2 at P = 2, 4 above; MGGCN_DIST_CHUNKS overrides.
+inline std::size_t mggcn_default_chunks(std::size_t P) {
+    if (const char *s = std::getenv("MGGCN_DIST_CHUNKS")) return std::max<std::size_t>(1, std::strtoull(s, nullptr, 10));
+    return P <= 1 ? 1 : (P == 2 ? 2 : 4);
+}
+
 // ---------------------------------------------------------------------------------------
 // dist_row_csr_matrix: A cut into a P x P grid of CSR blocks, block (i,j) = rows of GPU i x
-// rows-of-H of GPU j with block-local column indices (reference :215-259); in addition every
-// row block keeps its "remote" part (all blocks but the diagonal one, merged, GLOBAL columns)
-// for the all-gather schedule of ops.hpp.
+// rows-of-H of GPU j with block-local column indices (reference :215-259).  For the MI355X
+// schedules of ops.hpp every row block additionally keeps
+//   * its "remote" part (all blocks but the diagonal one, merged) cut into K pieces by the
+//     piece of the source shard a column lives in, columns renumbered to the layout one
+//     all-gather of that piece produces                               (all-gather schedule)
+//   * the halo form: need(i,s) = distinct rows of shard s that row block i references, and the
+//     remote part renumbered to the receive layout [need(i,0) | need(i,1) | ...]   (halo schedule)
 // ---------------------------------------------------------------------------------------
 template <typename x_t, typename v_t, typename r_t>
 class dist_row_csr_matrix {
     using matrix_t = csr_matrix<x_t, v_t, r_t>;
     std::vector<std::vector<matrix_t>> As;
-    std::vector<matrix_t> remote_;
+    std::vector<std::vector<matrix_t>> chunks_;       // [i][c]
+    std::vector<v_t> chunk_bounds_;                    // K + 1 row offsets inside a shard
+    std::vector<matrix_t> halo_remote_;                // [i]
+    std::vector<std::vector<std::vector<v_t>>> need_;  // [i][s]
     std::vector<v_t> p_;
     std::size_t M_ = 0;
 
@@ -97,29 +123,85 @@ class dist_row_csr_matrix {
         return out;
     }
 
+    // The off-diagonal blocks of row block i merged into ONE CSR (row order and, inside a row, source-rank
+    // order then original order kept) with the column of entry (block s, local column l) given by col(s, l).
+    template <typename F>
+    static matrix_t merge_remote(const std::vector<matrix_t> &blocks, std::size_t i, v_t n_cols, F &&col) {
+        const v_t rows = blocks[0].n();
+        std::vector<x_t> ptr(rows + 1, 0);
+        std::vector<v_t> idx;
+        std::vector<r_t> dat;
+        std::size_t total = 0;
+        for (std::size_t s = 0; s < blocks.size(); s++) if (s != i) total += blocks[s].nnz();
+        idx.reserve(total);
+        dat.reserve(total);
+        for (v_t r = 0; r < rows; r++) {
+            for (std::size_t s = 0; s < blocks.size(); s++) {
+                if (s == i) continue;
+                const auto &b = blocks[s];
+                for (auto e = b.begin(r); e < b.end(r); e++) { idx.push_back(col(s, b.indices()[e])); dat.push_back(b.data()[e]); }
+            }
+            ptr[r + 1] = (x_t)idx.size();
+        }
+        return matrix_t(std::move(ptr), std::move(idx), std::move(dat), n_cols);
+    }
+
 public:
     dist_row_csr_matrix() = default;
 
-    dist_row_csr_matrix(const dist_context &, const matrix_t A, const std::vector<v_t> p, const std::vector<v_t> q)
+    dist_row_csr_matrix(const dist_context &, const matrix_t A, const std::vector<v_t> p, const std::vector<v_t> q,
+                        std::size_t chunks = 0)
         : p_(p), M_(A.m()) {
         assert(p == q);                                   // the only use in the reference (src/main.cpp:148-149)
-        for (std::size_t i = 0; i + 1 < p.size(); i++) {
+        const std::size_t P = p.size() - 1;
+        const v_t rows = p[1] - p[0];                     // equal shards (N % P == 0, reference :428)
+        std::size_t K = chunks ? chunks : mggcn_default_chunks(P);
+        K = std::max<std::size_t>(1, std::min<std::size_t>(K, std::max<v_t>(rows, 1)));
+        for (std::size_t c = 0; c <= K; c++) chunk_bounds_.push_back((v_t)(c * (std::size_t)rows / K));
+        std::vector<v_t> piece_of(rows);
+        for (std::size_t c = 0; c < K; c++)
+            for (v_t l = chunk_bounds_[c]; l < chunk_bounds_[c + 1]; l++) piece_of[l] = (v_t)c;
+        for (std::size_t i = 0; i < P; i++) {
             As.push_back(split_rows(A, p[i], p[i + 1], q));
-            // remote part: cut at [0, p_i, p_{i+1}, n], merge the two outer pieces with global columns
-            const auto three = split_rows(A, p[i], p[i + 1], std::vector<v_t>{0, p[i], p[i + 1], (v_t)A.m()});
-            const auto &L = three[0], &R = three[2];
-            const v_t rows = p[i + 1] - p[i];
-            std::vector<x_t> ptr(rows + 1, 0);
-            std::vector<v_t> idx;
-            std::vector<r_t> dat;
-            idx.reserve(L.nnz() + R.nnz());
-            dat.reserve(L.nnz() + R.nnz());
-            for (v_t r = 0; r < rows; r++) {
-                for (auto e = L.begin(r); e < L.end(r); e++) { idx.push_back(L.indices()[e]); dat.push_back(L.data()[e]); }
-                for (auto e = R.begin(r); e < R.end(r); e++) { idx.push_back(R.indices()[e] + p[i + 1]); dat.push_back(R.data()[e]); }
-                ptr[r + 1] = (x_t)idx.size();
+            const auto &blocks = As.back();
+            // (a) all-gather schedule: piece c gathers rows cb[c]..cb[c+1] of EVERY shard in rank order, so
+            //     entry (s, l) of piece c = piece_of[l] lands at column s * len_c + (l - cb[c])
+            chunks_.emplace_back();
+            for (std::size_t c = 0; c < K; c++) {
+                const v_t lo = chunk_bounds_[c], len = chunk_bounds_[c + 1] - lo;
+                std::vector<matrix_t> masked;                      // the blocks restricted to this piece's columns
+                for (std::size_t s = 0; s < P; s++) {
+                    if (s == i) { masked.emplace_back(std::vector<x_t>(rows + 1, 0), std::vector<v_t>{}, std::vector<r_t>{}, len); continue; }
+                    const auto &b = blocks[s];
+                    std::vector<x_t> ptr(rows + 1, 0);
+                    std::vector<v_t> idx;
+                    std::vector<r_t> dat;
+                    for (v_t r = 0; r < rows; r++) {
+                        for (auto e = b.begin(r); e < b.end(r); e++)
+                            if (piece_of[b.indices()[e]] == c) { idx.push_back(b.indices()[e] - lo); dat.push_back(b.data()[e]); }
+                        ptr[r + 1] = (x_t)idx.size();
+                    }
+                    masked.emplace_back(std::move(ptr), std::move(idx), std::move(dat), len);
+                }
+                chunks_.back().push_back(merge_remote(masked, i, (v_t)(P * len), [&](std::size_t s, v_t l) { return (v_t)(s * len + l); }));
             }
-            remote_.emplace_back(std::move(ptr), std::move(idx), std::move(dat), (v_t)A.m());
+            // (b) halo schedule: distinct referenced rows per source shard, receive layout in source order
+            need_.emplace_back(P);
+            std::vector<v_t> off(P + 1, 0);
+            for (std::size_t s = 0; s < P; s++) {
+                if (s != i) {
+                    auto &nd = need_.back()[s];
+                    nd = blocks[s].indices();
+                    std::sort(nd.begin(), nd.end());
+                    nd.erase(std::unique(nd.begin(), nd.end()), nd.end());
+                }
+                off[s + 1] = off[s] + (v_t)need_.back()[s].size();
+            }
+            const auto &need_i = need_.back();
+            halo_remote_.push_back(merge_remote(blocks, i, std::max<v_t>(off[P], 1), [&](std::size_t s, v_t l) {
+                const auto &nd = need_i[s];
+                return (v_t)(off[s] + (std::lower_bound(nd.begin(), nd.end(), l) - nd.begin()));
+            }));
         }
     }
 
@@ -127,8 +209,21 @@ public:
     auto m() const { return M_; }
     auto size() const { return As.size(); }
     auto operator[](std::pair<std::size_t, std::size_t> ij) const { return As[ij.first][ij.second]; }
-    const matrix_t &remote(std::size_t i) const { return remote_[i]; }
     const std::vector<v_t> &bounds() const { return p_; }
+    // all-gather schedule
+    std::size_t chunks() const { return chunk_bounds_.size() - 1; }
+    const std::vector<v_t> &chunk_bounds() const { return chunk_bounds_; }
+    const matrix_t &remote_chunk(std::size_t i, std::size_t c) const { return chunks_[i][c]; }
+    // halo schedule
+    const matrix_t &halo_remote(std::size_t i) const { return halo_remote_[i]; }
+    const std::vector<v_t> &halo_need(std::size_t i, std::size_t s) const { return need_[i][s]; }
+    // rows moved per (receiver, source) pair: the matrix test/data/prep.py:237-244 prints for a partition
+    std::vector<std::vector<std::size_t>> halo_volume() const {
+        std::vector<std::vector<std::size_t>> V(size(), std::vector<std::size_t>(size(), 0));
+        for (std::size_t i = 0; i < size(); i++)
+            for (std::size_t s = 0; s < size(); s++) V[i][s] = need_[i][s].size();
+        return V;
+    }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -176,13 +271,22 @@ public:
         mggcn_comm_broadcast_f32(ctx.comm(), As[i].buffer(), recv.data(), As[i].size(), (int)i, streams.data());
     }
 
-    // all shards to every GPU's gathered[j] ([n x m]): the MI355X-first exchange
-    void allgather(const dist_context &ctx, const std::vector<matrix_t> &gathered, int stream_id = 1) const {
+    // rows [row_begin, row_end) of EVERY shard to every GPU, rank order, at gathered[j] + P * row_begin * m:
+    // one piece of the MI355X-first exchange (the whole shard when the range is the whole shard)
+    void allgather(const dist_context &ctx, const std::vector<matrix_t> &gathered, std::size_t row_begin, std::size_t row_end,
+                   int stream_id = 1) const {
         std::vector<const float *> send;
         std::vector<float *> recv;
-        for (std::size_t j = 0; j < size(); j++) { send.push_back(As[j].buffer()); recv.push_back(gathered[j].buffer()); }
+        const std::size_t P = size(), w = m();
+        for (std::size_t j = 0; j < P; j++) {
+            send.push_back(As[j].buffer() + row_begin * w);
+            recv.push_back(gathered[j].buffer() + P * row_begin * w);
+        }
         const auto streams = ctx.streams(stream_id);
-        mggcn_comm_allgather_f32(ctx.comm(), send.data(), recv.data(), As[0].size(), streams.data());
+        mggcn_comm_allgather_f32(ctx.comm(), send.data(), recv.data(), (row_end - row_begin) * w, streams.data());
+    }
+    void allgather(const dist_context &ctx, const std::vector<matrix_t> &gathered, int stream_id = 1) const {
+        allgather(ctx, gathered, 0, As[0].n(), stream_id);
     }
 
     void zero(const dist_context &ctx) const { for (std::size_t i = 0; i < size(); i++) As[i].zero(ctx[i]); }
@@ -212,6 +316,10 @@ public:
         for (std::size_t i = 0; i < ctx.size(); i++) { ctx[i].set(); As.emplace_back(N, M); }
     }
     repl_dn_matrix(const dist_context &ctx, std::pair<std::size_t, std::size_t> s) : repl_dn_matrix(ctx, s.first, s.second) {}
+    // views of caller-owned per-GPU buffers (G_W and G_b of a layer share one: a single all-reduce)
+    repl_dn_matrix(const dist_context &ctx, std::size_t N, std::size_t M, const std::vector<mggcn::device_ptr<r_t>> &buffers) {
+        for (std::size_t i = 0; i < ctx.size(); i++) { ctx[i].set(); As.emplace_back(N, M, buffers[i]); }
+    }
 
     auto n() const { return As[0].n(); }
     auto m() const { return As[0].m(); }
@@ -219,11 +327,11 @@ public:
     auto size() const { return As.size(); }
     const matrix_t &operator[](std::size_t i) const { return As[i]; }
 
-    // in-place sum over the GPUs (reference :587-592)
-    void allreduce(const dist_context &ctx) const {
+    // in-place sum over the GPUs (reference :587-592), on stream `stream_id` of every GPU
+    void allreduce(const dist_context &ctx, int stream_id = 0) const {
         std::vector<float *> bufs;
         for (const auto &A : As) bufs.push_back(A.buffer());
-        const auto streams = ctx.streams(0);
+        const auto streams = ctx.streams(stream_id);
         mggcn_comm_allreduce_sum_f32(ctx.comm(), bufs.data(), As[0].size(), streams.data());
     }
 

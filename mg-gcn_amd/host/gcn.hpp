@@ -56,10 +56,10 @@ class dist_sparse_linear {
     std::string name;
     csr_t A, A_T;
     std::vector<mggcn::device_ptr<r_t>> bcast_buffer, bcast_buffer2;
-    bool rounds;
-    std::size_t M = 0, M2 = 0;
+    dist_mode mode;
     dist_spmm_buffers ext, ext2;
-    bool have_ext = false, have_ext2 = false;
+    std::size_t M = 0, M2 = 0;                     // width the buffers were built for (reference :28-31)
+    std::shared_ptr<dist_halo_plan<r_t>> halo, halo2;
 
     // receive buffers as matrices of the current width
     std::vector<dn_t> round_views(const dist_context &ctx, const dn_t &B) const {
@@ -71,21 +71,30 @@ class dist_sparse_linear {
         return g;
     }
 
+    void run(const dist_context &ctx, const csr_t &Mx, dn_t B, dn_t C, dist_spmm_buffers &e, std::size_t &width,
+             std::shared_ptr<dist_halo_plan<r_t>> &hp, r_t beta, const std::string &tag, uint32_t flags) {
+        if (width != B.m()) { e = get_matmul_buffer(ctx, Mx, B, C, mode); width = B.m(); }
+        switch (mode) {
+            case dist_mode::rounds: matmul(ctx, Mx, B, C, e, round_views(ctx, B), (r_t)1, beta, name + tag, flags); break;
+            case dist_mode::allgather: matmul_allgather(ctx, Mx, B, C, e, gather_views(ctx, B), (r_t)1, beta, name + tag, flags); break;
+            case dist_mode::halo:
+                if (!hp) hp = std::make_shared<dist_halo_plan<r_t>>(ctx, Mx);
+                matmul_halo(ctx, Mx, B, C, e, *hp, gather_views(ctx, B), (r_t)1, beta, name + tag, flags);
+                break;
+        }
+    }
+
 public:
     dist_sparse_linear(std::string name, csr_t A, csr_t A_T, std::vector<mggcn::device_ptr<r_t>> bcast_buffer,
-                       std::vector<mggcn::device_ptr<r_t>> bcast_buffer2, bool rounds = false)
-        : name(name), A(A), A_T(A_T), bcast_buffer(bcast_buffer), bcast_buffer2(bcast_buffer2), rounds(rounds) {}
+                       std::vector<mggcn::device_ptr<r_t>> bcast_buffer2, dist_mode mode = dist_mode::allgather)
+        : name(name), A(A), A_T(A_T), bcast_buffer(bcast_buffer), bcast_buffer2(bcast_buffer2), mode(mode) {}
 
     void operator()(const dist_context ctx, dn_t B, dn_t C, bool discard = true, uint32_t flags = 0) {
-        if (!have_ext) { ext = get_matmul_buffer(ctx, A, B, C, rounds); have_ext = true; }
-        if (rounds) matmul(ctx, A, B, C, ext, round_views(ctx, B), (r_t)1, discard ? (r_t)0 : (r_t)1, name + "0_", flags);
-        else matmul_allgather(ctx, A, B, C, ext, gather_views(ctx, B), (r_t)1, discard ? (r_t)0 : (r_t)1, name + "0_", flags);
+        run(ctx, A, B, C, ext, M, halo, discard ? (r_t)0 : (r_t)1, "0_", flags);
     }
 
     void backward(const dist_context ctx, dn_t G, dn_t G_out, bool discard = true) {
-        if (!have_ext2) { ext2 = get_matmul_buffer(ctx, A_T, G, G_out, rounds); have_ext2 = true; }
-        if (rounds) matmul(ctx, A_T, G, G_out, ext2, round_views(ctx, G), (r_t)1, discard ? (r_t)0 : (r_t)1, name + "1_");
-        else matmul_allgather(ctx, A_T, G, G_out, ext2, gather_views(ctx, G), (r_t)1, discard ? (r_t)0 : (r_t)1, name + "1_");
+        run(ctx, A_T, G, G_out, ext2, M2, halo2, discard ? (r_t)0 : (r_t)1, "1_", 0u);
     }
 };
 
@@ -140,14 +149,17 @@ public:
         this->X = X;
     }
 
-    void backward(context ctx, dn_t G, dn_t G_out, bool discard = true) {
+    // mask (fused path): the activated output Z of the layer below; G_out leaves the GEMM already multiplied by
+    // leaky_relu'(Z), i.e. it IS that layer's T (reference :462-468)
+    void backward(context ctx, dn_t G, dn_t G_out, bool discard = true, const dn_t *mask = nullptr) {
         if (ones.n() != 1 || ones.m() != G.n()) { ones = dn_t(1, G.n()); ones.fill(1); }
         ctx.record(name + "1_0_matmul-gemm", 0);
         matmul(ctx, ones, G, G_b, (r_t)1, (r_t)0);
         ctx.record(name + "1_1_matmul-gemm", 0);
         matmul(ctx, X, G, G_W, (r_t)1, (r_t)0, true);
         ctx.record(name + "1_2_matmul-gemm", 0);
-        if (backward_out) matmul(ctx, G, W, G_out, (r_t)1, discard ? (r_t)0 : (r_t)1, false, true);
+        if (backward_out && mask) matmul_lrelu_backward(ctx, G, W, *mask, G_out, (r_t)1, false, true);
+        else if (backward_out) matmul(ctx, G, W, G_out, (r_t)1, discard ? (r_t)0 : (r_t)1, false, true);
         ctx.record(name + "1_3_matmul-gemm", 0);
         ctx.register_timer(name + "1_matmul-gemm", name + "1_0_matmul-gemm", name + "1_3_matmul-gemm");
     }
@@ -157,12 +169,24 @@ public:
         axpy(ctx, G_b, b, -lr);
     }
 
-    void adam_update(context ctx, const r_t lr, const r_t beta1, const r_t beta2, const r_t weight_decay, const r_t eps) {
+    bool has_backward_out() const { return backward_out; }
+
+    // Adam moments, zeroed on first use; bump_step() for the model-wide single launch (gcn::adam_update)
+    void adam_state(context ctx) {
         if (mW.shape() != W.shape()) {
             mW = dn_t(W.shape()); vW = dn_t(W.shape()); mb = dn_t(b.shape()); vb = dn_t(b.shape());
             mW.zero(ctx); vW.zero(ctx); mb.zero(ctx); vb.zero(ctx);
             step = 0;
         }
+    }
+    std::size_t bump_step() { return ++step; }
+    void adam_tensors(std::vector<std::array<dn_t, 4>> &out, std::vector<r_t> &wd, r_t weight_decay) const {
+        out.push_back({W, G_W, mW, vW}); wd.push_back(weight_decay);       // W decays, b does not (reference :163)
+        out.push_back({b, G_b, mb, vb}); wd.push_back((r_t)0);
+    }
+
+    void adam_update(context ctx, const r_t lr, const r_t beta1, const r_t beta2, const r_t weight_decay, const r_t eps) {
+        adam_state(ctx);
         step += 1;
         ctx.record(name + "0_adam-update", 0);
         adam_step(ctx, fused, W, G_W, mW, vW, b, G_b, mb, vb, lr, beta1, beta2, weight_decay, eps, step);
@@ -181,14 +205,39 @@ class dist_row_linear {
     using dn_t = dist_row_dn_matrix<r_t>;
     using rdn_t = repl_dn_matrix<r_t>;
     std::string name;
-    rdn_t W, G_W, mW, vW, b, G_b, mb, vb, ones;
+    // G_W and G_b of a layer live in ONE buffer per GPU: [G_W | pad to 4 floats | G_b] -> a single in-place
+    // all-reduce per layer (the reference all-reduces them separately, :236-240), run on the comm stream
+    // while the backward pass goes on; awaited by finish_backward() / adam_update()
+    std::vector<mggcn::device_ptr<r_t>> G_flat;
+    std::size_t off_b = 0, flat_len = 0;
+    rdn_t W, G_W, mW, vW, b, G_b, mb, vb, ones, G_all;
     dn_t X;
-    bool backward_out, fused;
+    bool backward_out, fused, pending = false;
     std::size_t step = 0;
+
+    static std::vector<mggcn::device_ptr<r_t>> alloc_flat(const dist_context &ctx, std::size_t len) {
+        std::vector<mggcn::device_ptr<r_t>> t;
+        for (std::size_t i = 0; i < ctx.size(); i++) {
+            ctx[i].set();
+            t.push_back(mggcn::device_malloc<r_t>(len));
+            mggcn_memset_zero(t.back().get(), len * sizeof(r_t), ctx[i].stream(0));     // the padding takes part in the sum
+        }
+        return t;
+    }
+    static std::vector<mggcn::device_ptr<r_t>> views(const std::vector<mggcn::device_ptr<r_t>> &owner, std::size_t off) {
+        std::vector<mggcn::device_ptr<r_t>> t;
+        for (const auto &o : owner) t.push_back(mggcn::device_view(o, off));
+        return t;
+    }
 
 public:
     dist_row_linear(const dist_context ctx, std::string name, std::size_t in, std::size_t out, bool backward_out = true, bool fused = false)
-        : name(name), W(ctx, in, out), G_W(ctx, in, out), b(ctx, 1, out), G_b(ctx, 1, out), backward_out(backward_out), fused(fused) {
+        : name(name), off_b((in * out + 3) / 4 * 4), flat_len(off_b + out), W(ctx, in, out), b(ctx, 1, out),
+          backward_out(backward_out), fused(fused) {
+        G_flat = alloc_flat(ctx, flat_len);
+        G_W = rdn_t(ctx, in, out, G_flat);
+        G_b = rdn_t(ctx, 1, out, views(G_flat, off_b));
+        G_all = rdn_t(ctx, 1, flat_len, G_flat);
         W.init(ctx);
         b.init(ctx, std::sqrt((r_t)1.0 / 3));
     }
@@ -209,25 +258,51 @@ public:
         this->X = X;
     }
 
-    void backward(dist_context ctx, dn_t G, dn_t G_out, bool discard = true) {
-        if (ones.size() != ctx.size()) { ones = rdn_t(ctx, 1, G.n() / ctx.size()); ones.fill(ctx, 1); }
+    void backward(dist_context ctx, dn_t G, dn_t G_out, bool discard = true, const dn_t *mask = nullptr) {
+        if (ones.size() != ctx.size() || ones.m() != G.n() / ctx.size()) { ones = rdn_t(ctx, 1, G.n() / ctx.size()); ones.fill(ctx, 1); }
+        const int cs = ctx.bcast_stream_id();
         ctx.record(name + "1_0_matmul-gemm", 0);
-        for (std::size_t i = 0; i < ctx.size(); i++) matmul(ctx[i], ones[i], G[i], G_b[i], (r_t)1, (r_t)0);
-        G_b.allreduce(ctx);
-        ctx.record(name + "1_1_matmul-gemm", 0);
-        matmul(ctx, X, G, G_W, (r_t)1, (r_t)0);                    // per-GPU X_i^T G_i + all-reduce
+        for (std::size_t i = 0; i < ctx.size(); i++) {
+            matmul(ctx[i], ones[i], G[i], G_b[i], (r_t)1, (r_t)0);            // G_b = 1^T G      (local part)
+            matmul(ctx[i], X[i], G[i], G_W[i], (r_t)1, (r_t)0, true);         // G_W = X^T G      (local part)
+        }
+        ctx.record(name + "1_1_grad-local", 0);
+        ctx.wait(name + "1_1_grad-local", cs);
+        G_all.allreduce(ctx, cs);                                             // [G_W | G_b] summed over the GPUs
+        ctx.record(name + "1_2_grad-reduced", cs);
+        pending = true;
         ctx.record(name + "1_2_matmul-gemm", 0);
-        if (backward_out) matmul(ctx, G, W, G_out, (r_t)1, discard ? (r_t)0 : (r_t)1, true);
+        if (backward_out && mask)
+            for (std::size_t i = 0; i < ctx.size(); i++) matmul_lrelu_backward(ctx[i], G[i], W[i], (*mask)[i], G_out[i], (r_t)1, false, true);
+        else if (backward_out) matmul(ctx, G, W, G_out, (r_t)1, discard ? (r_t)0 : (r_t)1, true);
         ctx.record(name + "1_3_matmul-gemm", 0);
         ctx.register_timer(name + "1_matmul-gemm", name + "1_0_matmul-gemm", name + "1_3_matmul-gemm");
     }
 
-    void adam_update(dist_context ctx, const r_t lr, const r_t beta1, const r_t beta2, const r_t weight_decay, const r_t eps) {
+    // the compute stream sees the summed gradients from here on
+    void finish_backward(const dist_context ctx) {
+        if (pending) ctx.wait(name + "1_2_grad-reduced", 0);
+        pending = false;
+    }
+
+    bool has_backward_out() const { return backward_out; }
+
+    void adam_state(dist_context ctx) {
         if (mW.size() != W.size()) {
             mW = rdn_t(ctx, W.shape()); vW = rdn_t(ctx, W.shape()); mb = rdn_t(ctx, b.shape()); vb = rdn_t(ctx, b.shape());
             mW.zero(ctx); vW.zero(ctx); mb.zero(ctx); vb.zero(ctx);
             step = 0;
         }
+    }
+    std::size_t bump_step() { return ++step; }
+    void adam_tensors(std::size_t gpu, std::vector<std::array<dn_matrix<r_t>, 4>> &out, std::vector<r_t> &wd, r_t weight_decay) const {
+        out.push_back({W[gpu], G_W[gpu], mW[gpu], vW[gpu]}); wd.push_back(weight_decay);
+        out.push_back({b[gpu], G_b[gpu], mb[gpu], vb[gpu]}); wd.push_back((r_t)0);
+    }
+
+    void adam_update(dist_context ctx, const r_t lr, const r_t beta1, const r_t beta2, const r_t weight_decay, const r_t eps) {
+        finish_backward(ctx);
+        adam_state(ctx);
         step += 1;
         ctx.record(name + "0_adam-update", 0);
         for (std::size_t i = 0; i < ctx.size(); i++)
@@ -247,22 +322,40 @@ class gcn_layer {
     std::string name;
     sparse_linear<x_t, v_t, r_t> A;
     linear<r_t> lin;
+    std::optional<linear<r_t>> res_lin;   // residual connection when in != out (reference :418, :430)
+    bool residual_layer;
     dn_matrix<r_t> HW;                    // HW_buffer
     mggcn::device_ptr<r_t> AHW_buffer;
     dn_matrix<r_t> AHW, G_HW, G_out;      // AHW_buffer / HW_buffer / AHW_buffer
     bool activation, backward_spmm, fused;
     dn_matrix<r_t> H;
+    // fused backward (set by the model): mask_input_grad -- my G_out GEMM applies leaky_relu'(H) of the layer
+    // below; grad_premasked -- the G I receive already carries my own activation's mask
+    bool mask_input_grad = false, grad_premasked = false;
 
 public:
+    bool gemm_first() const { return HW.m() == AHW.m(); }           // out <= in (reference :439)
+    bool has_activation() const { return activation; }
+    bool propagates() const { return lin.has_backward_out(); }
+    void set_fused_backward(bool mask_input, bool premasked) { if (mask_input) mask_input_grad = true; if (premasked) grad_premasked = true; }
+    linear<r_t> &linear_layer() { return lin; }
+
     gcn_layer(std::string name, csr_matrix<x_t, v_t, r_t> A, csr_matrix<x_t, v_t, r_t> A_T, std::size_t in, std::size_t out,
               bool activation, bool residual_layer = false, bool backward_spmm = true,
               mggcn::device_ptr<r_t> HW_buffer = nullptr, bool fused = false)
         : name(name), A(name, A, A_T), lin(name, in, out, backward_spmm, fused),
+          res_lin(in == out || !residual_layer ? std::nullopt : std::make_optional(linear<r_t>(name, in, out, backward_spmm, false))),
+          residual_layer(residual_layer),
           HW(A.m(), std::min(in, out), HW_buffer ? HW_buffer : mggcn::device_malloc<r_t>(std::max<std::size_t>(A.m(), A_T.n()) * std::min(in, out))),
           AHW_buffer(mggcn::device_malloc<r_t>(std::max((std::size_t)A.n() * out, (std::size_t)A_T.n() * in))),
           AHW(A.n(), out, AHW_buffer), G_HW(A_T.n(), std::min(in, out), HW.shared_buffer()), G_out(A_T.n(), in, AHW_buffer),
-          activation(activation), backward_spmm(backward_spmm), fused(fused) {
-        if (residual_layer) throw std::invalid_argument("residual_layer is never enabled by the reference CLI");
+          activation(activation), backward_spmm(backward_spmm), fused(fused) {}
+
+    bool has_residual() const { return residual_layer; }
+    std::vector<linear<r_t> *> linears() {
+        std::vector<linear<r_t> *> v{&lin};
+        if (res_lin) v.push_back(&*res_lin);
+        return v;
     }
 
     auto operator()(context ctx, dn_matrix<r_t> H) {
@@ -282,12 +375,14 @@ public:
             ctx.record(name + "0_1_activation", 0);
             ctx.register_timer(name + "0_activation", name + "0_0_activation", name + "0_1_activation");
         }
+        if (res_lin) (*res_lin)(ctx, H, AHW, false);          // reference :453-456
+        else if (residual_layer) axpy(ctx, H, AHW, (r_t)1);
         return AHW;
     }
 
     auto backward(context ctx, dn_matrix<r_t> G) {
         auto T = G;
-        if (activation) {
+        if (activation && !grad_premasked) {
             ctx.record(name + "1_0_activation", 0);
             leaky_relu_backward(ctx, AHW, G, AHW);
             ctx.record(name + "1_1_activation", 0);
@@ -297,17 +392,26 @@ public:
         if (HW.m() == AHW.m()) {
             auto g = G_HW;
             if (backward_spmm) A.backward(ctx, T, g); else g = T;
-            lin.backward(ctx, g, G_out);
-            return G_out;
+            lin.backward(ctx, g, G_out, true, mask_input_grad ? &H : nullptr);
+            return residual_backward(ctx, G, G_out);
         }
         lin.setX(H);
         lin.backward(ctx, T, G_HW);
-        if (backward_spmm) { A.backward(ctx, G_HW, G_out); return G_out; }
-        return G_HW;
+        if (backward_spmm) { A.backward(ctx, G_HW, G_out); return residual_backward(ctx, G, G_out); }
+        return residual_backward(ctx, G, G_HW);
     }
 
-    void update(const context ctx, const r_t lr, const r_t wd) { lin.update(ctx, lr, wd); }
-    void adam_update(const context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) { lin.adam_update(ctx, lr, b1, b2, wd, eps); }
+    // reference :484-487: the residual branch sees the incoming (unmasked) gradient and adds to G_out
+    dn_matrix<r_t> residual_backward(context ctx, dn_matrix<r_t> G, dn_matrix<r_t> out) {
+        if (res_lin) res_lin->backward(ctx, G, out, false);
+        else if (residual_layer) axpy(ctx, G, out, (r_t)1);
+        return out;
+    }
+
+    void update(const context ctx, const r_t lr, const r_t wd) { for (auto *l : linears()) l->update(ctx, lr, wd); }
+    void adam_update(const context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) {
+        for (auto *l : linears()) l->adam_update(ctx, lr, b1, b2, wd, eps);
+    }
     auto b() { return lin.get_b(); }
     auto W() { return lin.get_W(); }
     auto GW() { return lin.get_G_W(); }
@@ -322,10 +426,13 @@ class dist_gcn_layer {
     std::string name;
     dist_sparse_linear<row_partition, x_t, v_t, r_t> A;
     dist_row_linear<r_t> lin;
+    std::optional<dist_row_linear<r_t>> res_lin;      // reference :527
+    bool residual_layer;
     bufs_t AHW_buffer;
     dn_t HW, AHW, G_HW, G_out;
     bool activation, backward_spmm, fused;
     dn_t H;
+    bool mask_input_grad = false, grad_premasked = false;     // see gcn_layer
 
     static bufs_t alloc(const dist_context &ctx, std::size_t per_gpu) {
         bufs_t t;
@@ -336,12 +443,19 @@ class dist_gcn_layer {
 public:
     dist_gcn_layer(const dist_context ctx, std::string name, csr_t A, csr_t A_T, std::size_t in, std::size_t out, bool activation,
                    bool residual_layer = false, bool backward_spmm = true, bufs_t HW_buffer = {}, bufs_t bcast_buffer = {},
-                   bufs_t bcast_buffer2 = {}, bool fused = false, bool rounds = false)
-        : name(name), A(name, A, A_T, bcast_buffer, bcast_buffer2, rounds), lin(ctx, name, in, out, backward_spmm, fused),
+                   bufs_t bcast_buffer2 = {}, bool fused = false, dist_mode mode = dist_mode::allgather)
+        : name(name), A(name, A, A_T, bcast_buffer, bcast_buffer2, mode), lin(ctx, name, in, out, backward_spmm, fused),
+          res_lin(in == out || !residual_layer ? std::nullopt : std::make_optional(dist_row_linear<r_t>(ctx, name, in, out, backward_spmm, false))),
+          residual_layer(residual_layer),
           AHW_buffer(alloc(ctx, std::max(A.n() * out, A_T.n() * in) / ctx.size())), HW(ctx, A.m(), std::min(in, out), HW_buffer),
           AHW(ctx, A.n(), out, AHW_buffer), G_HW(ctx, A_T.n(), std::min(in, out), HW_buffer), G_out(ctx, A_T.n(), in, AHW_buffer),
-          activation(activation), backward_spmm(backward_spmm), fused(fused) {
-        if (residual_layer) throw std::invalid_argument("residual_layer is never enabled by the reference CLI");
+          activation(activation), backward_spmm(backward_spmm), fused(fused) {}
+
+    bool has_residual() const { return residual_layer; }
+    std::vector<dist_row_linear<r_t> *> linears() {
+        std::vector<dist_row_linear<r_t> *> v{&lin};
+        if (res_lin) v.push_back(&*res_lin);
+        return v;
     }
 
     auto operator()(dist_context ctx, dn_t H) {
@@ -361,12 +475,26 @@ public:
             ctx.record(name + "0_1_activation", 0);
             ctx.register_timer(name + "0_activation", name + "0_0_activation", name + "0_1_activation");
         }
+        if (res_lin) (*res_lin)(ctx, H, AHW, false);          // reference :572-575
+        else if (residual_layer) for (std::size_t i = 0; i < ctx.size(); i++) axpy(ctx[i], H[i], AHW[i], (r_t)1);
         return AHW;
     }
 
+    dn_t residual_backward(dist_context ctx, dn_t G, dn_t out) {      // reference :603-606
+        if (res_lin) res_lin->backward(ctx, G, out, false);
+        else if (residual_layer) for (std::size_t i = 0; i < ctx.size(); i++) axpy(ctx[i], G[i], out[i], (r_t)1);
+        return out;
+    }
+
+    bool gemm_first() const { return HW.m() == AHW.m(); }
+    bool has_activation() const { return activation; }
+    bool propagates() const { return lin.has_backward_out(); }
+    void set_fused_backward(bool mask_input, bool premasked) { if (mask_input) mask_input_grad = true; if (premasked) grad_premasked = true; }
+    dist_row_linear<r_t> &linear_layer() { return lin; }
+
     auto backward(dist_context ctx, dn_t G) {
         auto T = G;
-        if (activation) {
+        if (activation && !grad_premasked) {
             ctx.record(name + "1_0_activation", 0);
             leaky_relu_backward(ctx, AHW, G, AHW);
             ctx.record(name + "1_1_activation", 0);
@@ -376,16 +504,19 @@ public:
         if (HW.m() == AHW.m()) {
             auto g = G_HW;
             if (backward_spmm) A.backward(ctx, T, g); else g = T;
-            lin.backward(ctx, g, G_out);
-            return G_out;
+            lin.backward(ctx, g, G_out, true, mask_input_grad ? &H : nullptr);
+            return residual_backward(ctx, G, G_out);
         }
         lin.setX(H);
         lin.backward(ctx, T, G_HW);
-        if (backward_spmm) { A.backward(ctx, G_HW, G_out); return G_out; }
-        return G_HW;
+        if (backward_spmm) { A.backward(ctx, G_HW, G_out); return residual_backward(ctx, G, G_out); }
+        return residual_backward(ctx, G, G_HW);
     }
 
-    void adam_update(const dist_context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) { lin.adam_update(ctx, lr, b1, b2, wd, eps); }
+    void finish_backward(const dist_context ctx) { for (auto *l : linears()) l->finish_backward(ctx); }
+    void adam_update(const dist_context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) {
+        for (auto *l : linears()) l->adam_update(ctx, lr, b1, b2, wd, eps);
+    }
     auto b() { return lin.get_b(); }
     auto W() { return lin.get_W(); }
     auto GW() { return lin.get_G_W(); }
@@ -515,6 +646,19 @@ public:
     auto backward() { return G; }
 };
 
+// fused backward: layer i+1's G_out GEMM applies layer i's leaky_relu' -- possible when layer i+1 is GEMM-first
+// (its G_out comes out of a GEMM, reference :479-481) and propagates a gradient at all
+template <typename layers_t>
+void link_fused_backward(layers_t &layers, bool fused) {
+    for (std::size_t i = 0; i + 1 < layers.size(); i++) {
+        // (a residual branch needs the UNMASKED incoming gradient and adds to G_out afterwards: no fusion there)
+        const bool ok = fused && layers[i].has_activation() && layers[i + 1].gemm_first() && layers[i + 1].propagates() &&
+                        !layers[i].has_residual() && !layers[i + 1].has_residual();
+        layers[i + 1].set_fused_backward(ok, false);
+        layers[i].set_fused_backward(false, ok);
+    }
+}
+
 template <typename x_t, typename v_t, typename r_t>
 class gcn {
     std::vector<gcn_layer<x_t, v_t, r_t>> layers_;
@@ -533,6 +677,8 @@ public:
         for (std::size_t i = 1; i < sizes.size(); i++)
             layers_.emplace_back(std::to_string(i - 1) + "_", A_T, A, sizes[i - 1], sizes[i], i + 1 < sizes.size(), residual_layer,
                                  i != 1, HW_buffer, fused);
+        link_fused_backward(layers_, fused);
+        fused_ = fused;
     }
 
     // test constructor with given weights (reference :957-963)
@@ -558,9 +704,30 @@ public:
     }
     void update(const context ctx, const r_t lr, const r_t wd) { for (auto &l : layers_) l.update(ctx, lr, wd); }
     void adam_update(const context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) {
-        for (auto &l : layers_) l.adam_update(ctx, lr, b1, b2, wd, eps);
+        if (!fused_) { for (auto &l : layers_) l.adam_update(ctx, lr, b1, b2, wd, eps); return; }
+        // ONE launch for every parameter tensor of the model (reference: 7 launches per layer, :146-172, :990-994)
+        std::size_t step = 0;
+        for (auto &l : layers_)
+            for (auto *lin : l.linears()) { lin->adam_state(ctx); step = lin->bump_step(); }
+        if (!adam_ || adam_wd_ != wd) {
+            std::vector<std::array<dn_matrix<r_t>, 4>> t;
+            std::vector<r_t> w;
+            for (auto &l : layers_)
+                for (auto *lin : l.linears()) lin->adam_tensors(t, w, wd);
+            adam_ = adam_table<r_t>(ctx, t, w);
+            adam_wd_ = wd;
+        }
+        ctx.record("0_adam-update", 0);
+        adam_.step(ctx, lr, b1, b2, (r_t)(1 - std::pow(b1, step)), (r_t)(1 - std::pow(b2, step)), eps);
+        ctx.record("1_adam-update", 0);
+        ctx.register_timer("adam-update", "0_adam-update", "1_adam-update");
     }
     auto &layers() { return layers_; }
+
+private:
+    bool fused_ = true;
+    adam_table<r_t> adam_;
+    r_t adam_wd_ = 0;
 };
 
 template <bool row_partition, typename x_t, typename v_t, typename r_t>
@@ -577,7 +744,7 @@ public:
     // per-GPU HW_buffer + receive buffers shared by all layers (reference :1016-1021).  The
     // all-gather schedule keeps the whole gathered B resident per GPU (n x max_d floats).
     dist_gcn(const dist_context ctx, csr_t A, csr_t A_T, std::vector<std::size_t> sizes, bool residual_layer = false,
-             bool fused = true, bool rounds = false)
+             bool fused = true, dist_mode mode = dist_mode::allgather)
         : loss_layer(std::to_string(sizes.size() - 1) + "_", residual_layer, fused) {
         std::size_t max_d = 0;
         for (std::size_t i = 0; i + 1 < sizes.size(); i++) max_d = std::max(max_d, std::min(sizes[i], sizes[i + 1]));
@@ -585,12 +752,14 @@ public:
         for (std::size_t i = 0; i < ctx.size(); i++) {
             ctx[i].set();
             HW_buffer.push_back(mggcn::device_malloc<r_t>(shard));
-            bcast_buffer.push_back(mggcn::device_malloc<r_t>(rounds ? shard : nmax * max_d));
+            bcast_buffer.push_back(mggcn::device_malloc<r_t>(mode == dist_mode::rounds ? shard : nmax * max_d));
             bcast_buffer2.push_back(mggcn::device_malloc<r_t>(shard));
         }
         for (std::size_t i = 1; i < sizes.size(); i++)
             layers_.emplace_back(ctx, std::to_string(i - 1) + "_", A_T, A, sizes[i - 1], sizes[i], i + 1 < sizes.size(), residual_layer,
-                                 i != 1, HW_buffer, bcast_buffer, bcast_buffer2, fused, rounds);
+                                 i != 1, HW_buffer, bcast_buffer, bcast_buffer2, fused, mode);
+        link_fused_backward(layers_, fused);
+        fused_ = fused;
     }
 
     auto operator()(const dist_context ctx, dn_t H) {
@@ -604,9 +773,36 @@ public:
     void backward(const dist_context ctx) {
         auto G = loss_layer.backward();
         for (auto l = layers_.rbegin(); l != layers_.rend(); l++) G = l->backward(ctx, G);
+        for (auto &l : layers_) l.finish_backward(ctx);           // gradients are summed over the GPUs from here on
     }
     void adam_update(const dist_context ctx, const r_t lr, const r_t b1, const r_t b2, const r_t wd, const r_t eps) {
-        for (auto &l : layers_) l.adam_update(ctx, lr, b1, b2, wd, eps);
+        if (!fused_) { for (auto &l : layers_) l.adam_update(ctx, lr, b1, b2, wd, eps); return; }
+        std::size_t step = 0;
+        for (auto &l : layers_) {
+            l.finish_backward(ctx);
+            for (auto *lin : l.linears()) { lin->adam_state(ctx); step = lin->bump_step(); }
+        }
+        if (adam_.size() != ctx.size() || adam_wd_ != wd) {
+            adam_.clear();
+            for (std::size_t g = 0; g < ctx.size(); g++) {
+                std::vector<std::array<dn_matrix<r_t>, 4>> t;
+                std::vector<r_t> w;
+                for (auto &l : layers_)
+                    for (auto *lin : l.linears()) lin->adam_tensors(g, t, w, wd);
+                adam_.emplace_back(ctx[g], t, w);
+            }
+            adam_wd_ = wd;
+        }
+        ctx.record("0_adam-update", 0);
+        for (std::size_t g = 0; g < ctx.size(); g++)
+            adam_[g].step(ctx[g], lr, b1, b2, (r_t)(1 - std::pow(b1, step)), (r_t)(1 - std::pow(b2, step)), eps);
+        ctx.record("1_adam-update", 0);
+        ctx.register_timer("adam-update", "0_adam-update", "1_adam-update");
     }
     auto &layers() { return layers_; }
+
+private:
+    bool fused_ = true;
+    std::vector<adam_table<r_t>> adam_;
+    r_t adam_wd_ = 0;
 };

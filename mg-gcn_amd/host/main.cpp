@@ -8,8 +8,10 @@
 // :130, :167), same per-epoch timer dump "csvs/<name>_<sizes>_<P>.csv" (:100-111, :131, :168),
 // same hyper-parameters (Adam 1e-2 / 0.9 / 0.999 / 5e-4 / 1e-8, :126).  Like the reference,
 // P > 1 trains only with -R 1 (row partition); classes are padded to a multiple of P (:135).
-// Environment: MGGCN_DIST_MODE=rounds selects the reference's broadcast pipeline instead of
-// the all-gather exchange; MGGCN_FUSED=0 replays the reference's launch sequence.
+// `-R 1` routes through the distributed classes at any P (at -P 1 too: one rank, same schedule).
+// Environment: MGGCN_DIST_MODE=allgather|halo|rounds picks the exchange schedule (ops.hpp; rounds = the
+// reference's broadcast pipeline); MGGCN_FUSED=0 replays the reference's launch sequence;
+// MGGCN_OVERSUBSCRIBE=1 lets -P exceed the visible GPUs (ranks wrap over them, peer-copy transport).
 #include <unistd.h>
 
 #include <chrono>
@@ -49,6 +51,17 @@ static int help_() {
     return EXIT_SUCCESS;
 }
 
+// MGGCN_DUMP_WEIGHTS=<dir>: before every epoch write each layer's W and b as dense .bin files
+// (<dir>/e<epoch>_W<layer>.bin, _b<layer>.bin; the reference's own dense format, u32 N, u32 M, f32 payload) so
+// that a checker can replay any epoch from the exact state it started in (tests/test_gpu_host_cpp.py).
+static void dump_dense(const std::filesystem::path &path, const dn_matrix<float> &A) {
+    const auto h = A.to_host();
+    std::ofstream out(path, std::ios::binary);
+    const std::uint32_t shape[2] = {(std::uint32_t)A.n(), (std::uint32_t)A.m()};
+    out.write(reinterpret_cast<const char *>(shape), sizeof shape);
+    out.write(reinterpret_cast<const char *>(h.data()), (std::streamsize)(h.size() * sizeof(float)));
+}
+
 static bool env_is(const char *name, const char *value) {
     const char *s = std::getenv(name);
     return s && std::string(s) == value;
@@ -73,14 +86,17 @@ int main_(int argc, char **argv) {
         }
     }
     const bool fused = !env_is("MGGCN_FUSED", "0");
-    const bool rounds = env_is("MGGCN_DIST_MODE", "rounds");
+    const char *mode_env = std::getenv("MGGCN_DIST_MODE");
+    const dist_mode mode = dist_mode_from_string(mode_env ? mode_env : "");
+    const bool oversubscribe = std::getenv("MGGCN_OVERSUBSCRIBE") && !env_is("MGGCN_OVERSUBSCRIBE", "0");
 
     while (optind < argc && argv[optind] != nullptr) {
         const std::string command = argv[optind++];
         if (command.rfind("train", 0) != 0) throw arg_error("Unknown command.");
         if (optind >= argc) throw arg_error("train needs a dataset directory.");
         const std::filesystem::path dir = argv[optind++];
-        if ((int)mggcn_device_count() < (int)std::max<std::size_t>(P, 1)) throw arg_error("not enough GPUs visible for -P");
+        if ((int)mggcn_device_count() < (int)std::max<std::size_t>(P, 1) && !(oversubscribe && mggcn_device_count() > 0))
+            throw arg_error("not enough GPUs visible for -P");
 
         mggcn_set_device(0);
         csr_matrix<x_t, v_t, r_t> A(dir / "graph.bin");
@@ -114,12 +130,19 @@ int main_(int argc, char **argv) {
         std::filesystem::create_directories("csvs");
         std::ofstream of("csvs/" + filename + "_" + std::to_string(P) + ".csv");
 
-        if (P <= 1) {
+        if (P <= 1 && !row_partition) {
             auto ctx = context(0);
             gcn<x_t, v_t, r_t> G(A, sizes, false, fused);
             ctx.sync();
             ctx.record("training-start", 0);
             for (std::size_t e = 0; e < num_epochs; e++) {
+                if (const char *dd = std::getenv("MGGCN_DUMP_WEIGHTS")) {
+                    std::filesystem::create_directories(dd);
+                    for (std::size_t l = 0; l < G.layers().size(); l++) {
+                        dump_dense(std::filesystem::path(dd) / ("e" + std::to_string(e) + "_W" + std::to_string(l) + ".bin"), G.layers()[l].W());
+                        dump_dense(std::filesystem::path(dd) / ("e" + std::to_string(e) + "_b" + std::to_string(l) + ".bin"), G.layers()[l].b());
+                    }
+                }
                 const auto start = std::chrono::system_clock::now();
                 auto [loss, acc] = G.train_forward(ctx, X, Y);
                 G.backward(ctx);
@@ -139,7 +162,7 @@ int main_(int argc, char **argv) {
             dist_row_dn_matrix<std::int32_t> Yd(ctx, Y);
             dist_row_csr_matrix<x_t, v_t, r_t> Ad(ctx, A, p, p);
             dist_row_csr_matrix<x_t, v_t, r_t> A_Td(ctx, A_T, p, p);
-            dist_gcn<true, x_t, v_t, r_t> G(ctx, Ad, A_Td, sizes, false, fused, rounds);
+            dist_gcn<true, x_t, v_t, r_t> G(ctx, Ad, A_Td, sizes, false, fused, mode);
             dist_row_dn_matrix<r_t> Xd(ctx, X);
             ctx.sync();
             ctx.record("training-start", 0);

@@ -37,7 +37,7 @@ public:
 // ---------------------------------------------------------------------------------------
 class context {
     struct state {
-        std::size_t rank = 0;
+        std::size_t rank = 0;     // device ordinal this context drives
         mggcn_stream_t streams[2] = {nullptr, nullptr};
         std::map<std::string, mggcn_event_t> events;
         std::map<std::string, std::pair<std::string, std::string>> timers;
@@ -106,6 +106,9 @@ public:
 template <typename r_t>
 class dn_matrix;
 
+// the reference's opaque cuSPARSE workspace (cuda_ptr<char>, src/cuda_utils.hpp:94-102) becomes the SpMM plan
+using spmm_buffer = std::shared_ptr<mggcn_spmm_plan>;
+
 // ---------------------------------------------------------------------------------------
 // csr_matrix: reference src/matrix.hpp:214-468
 // ---------------------------------------------------------------------------------------
@@ -122,6 +125,10 @@ class csr_matrix {
         mggcn::device_ptr<v_t> d_indices;
         mggcn::device_ptr<r_t> d_data;
         int device = -1;
+        // SpMM plans built from this matrix, keyed (device, narrow lanes-per-row class | 0 = wide): the
+        // layers of a model multiply by the same two matrices, so the plan (0.9 GB, ~1 s of host work at
+        // the Reddit shape) is built once and shared (ops.hpp: get_matmul_buffer)
+        std::map<std::pair<int, unsigned>, std::pair<unsigned, spmm_buffer>> plans;
     };
     std::shared_ptr<storage> st_ = std::make_shared<storage>();
 
@@ -201,6 +208,23 @@ public:
     void normalize(bool axis = false) {
         mggcn_csr_normalize_host(st_->N, st_->M, st_->indptr.data(), st_->indices.data(), st_->data.data(), axis);
         st_->d_indptr.reset();
+        st_->plans.clear();          // a sweep plan carries its own copy of the values
+    }
+
+    // plan of this matrix on the current device for feature width d (built on first use, shared by all
+    // holders of this matrix; any plan serves any width <= its max_d, the hint only picks the fast form)
+    spmm_buffer plan(std::size_t d) const {
+        const int dev = mggcn_get_device();
+        const unsigned form = (d >= 1 && d <= 64) ? (unsigned)((d + 15) / 16) : 0u;
+        const unsigned max_d = (unsigned)std::max<std::size_t>(d, 128);
+        auto &slot = st_->plans[{dev, form}];
+        if (!slot.second || slot.first < max_d) {
+            slot.second = spmm_buffer(mggcn_spmm_plan_create_for(st_->N, st_->M, st_->indptr.data(), st_->indices.data(),
+                                                                 st_->data.data(), max_d, (unsigned)d),
+                                      &mggcn_spmm_plan_destroy);
+            slot.first = max_d;
+        }
+        return slot.second;
     }
 
     // reference src/matrix.hpp:392-453

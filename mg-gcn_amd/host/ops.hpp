@@ -7,6 +7,7 @@
 // throw std::invalid_argument.
 #pragma once
 
+#include <array>
 #include <memory>
 #include <string>
 #include <vector>
@@ -18,18 +19,13 @@ inline void mggcn_require(bool ok, const char *what) {
     if (!ok) throw std::invalid_argument(what);
 }
 
-// the reference's opaque cuSPARSE workspace (cuda_ptr<char>) becomes the SpMM plan
-using spmm_buffer = std::shared_ptr<mggcn_spmm_plan>;
-
 // ---- SpMM ------------------------------------------------------------------------------
 template <typename x_t, typename v_t, typename r_t>
 spmm_buffer get_matmul_buffer(const context ctx, const csr_matrix<x_t, v_t, r_t> A, const dn_matrix<r_t> B,
                               const dn_matrix<r_t> C, const r_t = 1, const r_t = 0) {
     mggcn_require(A.m() == B.n() && A.n() == C.n() && B.m() == C.m(), "get_matmul_buffer: shape mismatch");
     ctx.set();
-    return spmm_buffer(mggcn_spmm_plan_create_for(A.n(), A.m(), A.indptr().data(), A.indices().data(), A.data().data(),
-                                                  (uint32_t)std::max<std::size_t>(B.m(), 128), (uint32_t)B.m()),
-                       &mggcn_spmm_plan_destroy);
+    return A.plan(B.m());           // built once per (matrix, device, form) and shared, see csr_matrix::plan
 }
 
 template <typename x_t, typename v_t, typename r_t>
@@ -69,36 +65,91 @@ void linear_forward(const context ctx, const dn_matrix<r_t> X, const dn_matrix<r
                         W.buffer(), W.m(), b.buffer(), XW.buffer(), XW.m(), ctx.gemm_workspace(ws), ws);
 }
 
+// G_out = (alpha G . op(W)) .* leaky_relu'(Z): the next leaky_relu_backward folded into the GEMM epilogue
+// (include/mggcn.h: mggcn_gemm_lrelu_bwd_f32; reference src/gcn.hpp:135-137 + :462-468)
+template <typename r_t>
+void matmul_lrelu_backward(const context ctx, const dn_matrix<r_t> A, const dn_matrix<r_t> B, const dn_matrix<r_t> Z,
+                           const dn_matrix<r_t> C, const r_t alpha, const bool A_T = false, const bool B_T = false,
+                           const r_t slope = 0.01f) {
+    auto A_n = A.n(), A_m = A.m(), B_n = B.n(), B_m = B.m();
+    if (A_T) std::swap(A_n, A_m);
+    if (B_T) std::swap(B_n, B_m);
+    mggcn_require(A_m == B_n && A_n == C.n() && B_m == C.m() && Z.shape() == C.shape(), "matmul_lrelu_backward: shape mismatch");
+    ctx.set();
+    const auto ws = mggcn_gemm_workspace_bytes(A_T, B_T, (uint32_t)A_n, (uint32_t)B_m, (uint32_t)A_m);
+    mggcn_gemm_lrelu_bwd_f32(ctx.stream(0), A_T, B_T, (uint32_t)A_n, (uint32_t)B_m, (uint32_t)A_m, alpha, A.buffer(), A.m(),
+                             B.buffer(), B.m(), Z.buffer(), Z.m(), slope, C.buffer(), C.m(), ctx.gemm_workspace(ws), ws);
+}
+
+// every (param, grad, m, v) quadruple of a model on one GPU as a device table: ONE Adam launch per epoch
+// (include/mggcn.h: mggcn_adam_multi_f32; reference src/gcn.hpp:146-172 runs 7 launches per layer)
+template <typename r_t>
+class adam_table {
+    mggcn::device_ptr<mggcn_adam_tensor> dev_;
+    std::vector<dn_matrix<r_t>> keep_;          // the table holds raw pointers
+    uint32_t n_ = 0, blocks_ = 0;
+
+public:
+    adam_table() = default;
+    // entries: {param, grad, m, v} + weight decay of each
+    adam_table(const context &ctx, const std::vector<std::array<dn_matrix<r_t>, 4>> &tensors, const std::vector<r_t> &wd) {
+        std::vector<mggcn_adam_tensor> tab;
+        for (std::size_t k = 0; k < tensors.size(); k++) {
+            const auto &t = tensors[k];
+            tab.push_back({t[0].buffer(), t[1].buffer(), t[2].buffer(), t[3].buffer(), (uint64_t)t[0].size(), wd[k], blocks_});
+            blocks_ += mggcn_adam_multi_blocks(t[0].size());
+            for (const auto &x : t) keep_.push_back(x);
+        }
+        n_ = (uint32_t)tab.size();
+        ctx.set();
+        dev_ = mggcn::device_malloc<mggcn_adam_tensor>(std::max<std::size_t>(tab.size(), 1));
+        if (!tab.empty()) mggcn::upload(dev_.get(), tab.data(), tab.size());
+    }
+    explicit operator bool() const { return n_ != 0; }
+    void step(const context &ctx, r_t lr, r_t b1, r_t b2, r_t c1, r_t c2, r_t eps) const {
+        ctx.set();
+        mggcn_adam_multi_f32(ctx.stream(0), dev_.get(), n_, blocks_, lr, b1, b2, c1, c2, eps);
+    }
+};
+
 // ---- distributed SpMM: C_j = beta C_j + alpha sum_i A[j,i] B_i ------------------------------
+// Three schedules of the same sum (MGGCN_DIST_MODE / dist_gcn's `mode`):
+//   allgather  K all-gathers of one piece of every shard each, queued back to back on the comm stream;
+//              diagonal block first (no dependency), then the K pieces of the merged remote block as
+//              they land -- the SpMM over piece c runs while piece c+1 is on the wire         (default)
+//   halo       every GPU packs the rows its peers' blocks reference, ONE variable-size exchange, the
+//              remote block renumbered to the receive layout                     
+//   rounds     the reference's P broadcast rounds, double-buffered            (src/cuda_utils.hpp:57-92)
+enum class dist_mode { allgather, rounds, halo };
+
+inline dist_mode dist_mode_from_string(const std::string &s) {
+    if (s == "rounds") return dist_mode::rounds;
+    if (s == "halo") return dist_mode::halo;
+    if (s.empty() || s == "allgather") return dist_mode::allgather;
+    throw std::invalid_argument("unknown distributed schedule '" + s + "' (allgather | halo | rounds)");
+}
+
 struct dist_spmm_buffers {
-    std::vector<std::vector<spmm_buffer>> block;   // [j][i]  (rounds schedule)
-    std::vector<spmm_buffer> remote;               // [j]     (all-gather schedule; diagonal = block[j][j])
+    std::vector<std::vector<spmm_buffer>> block;   // [j][i]  rounds: every block; otherwise only the diagonal [j][j]
+    std::vector<std::vector<spmm_buffer>> piece;   // [j][c]  all-gather schedule: pieces of the merged remote block
+    std::vector<spmm_buffer> halo;                 // [j]     halo schedule: remote block in receive layout
 };
 
 template <typename x_t, typename v_t, typename r_t>
 dist_spmm_buffers get_matmul_buffer(const dist_context ctx, const dist_row_csr_matrix<x_t, v_t, r_t> A,
-                                    const dist_row_dn_matrix<r_t> B, const dist_row_dn_matrix<r_t> C, bool rounds) {
+                                    const dist_row_dn_matrix<r_t> B, const dist_row_dn_matrix<r_t> C, dist_mode mode) {
     dist_spmm_buffers out;
     const auto P = ctx.size();
     out.block.resize(P);
+    out.piece.resize(P);
     for (std::size_t j = 0; j < P; j++) {
         ctx[j].set();
         out.block[j].resize(P);
         for (std::size_t i = 0; i < P; i++)
-            if (rounds || i == j) {
-                const auto blk = A[{j, i}];
-                out.block[j][i] = spmm_buffer(mggcn_spmm_plan_create_for(blk.n(), blk.m(), blk.indptr().data(), blk.indices().data(),
-                                                                         blk.data().data(), (uint32_t)std::max<std::size_t>(B.m(), 128),
-                                                                         (uint32_t)B.m()),
-                                              &mggcn_spmm_plan_destroy);
-            }
-        if (!rounds) {
-            const auto &rem = A.remote(j);
-            out.remote.push_back(spmm_buffer(mggcn_spmm_plan_create_for(rem.n(), rem.m(), rem.indptr().data(), rem.indices().data(),
-                                                                        rem.data().data(), (uint32_t)std::max<std::size_t>(B.m(), 128),
-                                                                        (uint32_t)B.m()),
-                                             &mggcn_spmm_plan_destroy));
-        }
+            if (mode == dist_mode::rounds || i == j) out.block[j][i] = A[{j, i}].plan(B.m());
+        if (mode == dist_mode::allgather && P > 1)
+            for (std::size_t c = 0; c < A.chunks(); c++) out.piece[j].push_back(A.remote_chunk(j, c).plan(B.m()));
+        if (mode == dist_mode::halo) out.halo.push_back(P > 1 ? A.halo_remote(j).plan(B.m()) : spmm_buffer());
     }
     (void)C;
     return out;
@@ -112,13 +163,14 @@ void matmul(dist_context ctx, dist_row_csr_matrix<x_t, v_t, r_t> A, dist_row_dn_
             const dist_spmm_buffers &ext, std::vector<dist_row_dn_matrix<r_t>> B_bcast, const r_t alpha, const r_t beta,
             const std::string name = "", const uint32_t last_flags = 0) {
     const auto P = ctx.size();
+    const int cs = ctx.bcast_stream_id();
     ctx.record(name + "0_matmul-spmm", 0);
-    ctx.wait(name + "0_matmul-spmm", 1);
+    ctx.wait(name + "0_matmul-spmm", cs);
     for (std::size_t i = 0; i < P; i++) {
-        if (i > 1) ctx.wait(name + std::to_string(i - 1) + "_matmul-spmm", ctx.bcast_stream_id());   // double-buffer hazard
-        ctx.record(name + std::to_string(i) + "_matmul-bcast-start", ctx.bcast_stream_id());
-        B.bcast(ctx, i, B_bcast[i % 2], ctx.bcast_stream_id());
-        ctx.record(name + std::to_string(i) + "_matmul-bcast-finish", ctx.bcast_stream_id());
+        if (i > 1) ctx.wait(name + std::to_string(i - 1) + "_matmul-spmm", cs);   // double-buffer hazard (:66-67)
+        ctx.record(name + std::to_string(i) + "_matmul-bcast-start", cs);
+        B.bcast(ctx, i, B_bcast[i % 2], cs);
+        ctx.record(name + std::to_string(i) + "_matmul-bcast-finish", cs);
         ctx.wait(name + std::to_string(i) + "_matmul-bcast-finish", 0);
         for (std::size_t j = 0; j < P; j++)
             matmul(ctx[j], A[{j, i}], B_bcast[i % 2][j], C[j], ext.block[j][i], alpha, i == 0 ? beta : (r_t)1,
@@ -128,26 +180,118 @@ void matmul(dist_context ctx, dist_row_csr_matrix<x_t, v_t, r_t> A, dist_row_dn_
     ctx.register_timer(name + "matmul-spmm", name + "0_matmul-spmm", name + std::to_string(P) + "_matmul-spmm");
 }
 
-// MI355X-first schedule: ONE all-gather of the shards on the comm stream, overlapped with
-// the SpMM of the diagonal block (no dependency); the merged remote blocks follow (beta = 1).
+// MI355X-first schedule.  gathered[j]: resident [n x d] receive buffer of GPU j; piece c occupies rows
+// P*cb[c] .. P*cb[c+1] of it (rank-major inside the piece), which is the column layout of A.remote_chunk(j, c).
 template <typename x_t, typename v_t, typename r_t>
 void matmul_allgather(dist_context ctx, dist_row_csr_matrix<x_t, v_t, r_t> A, dist_row_dn_matrix<r_t> B,
                       dist_row_dn_matrix<r_t> C, const dist_spmm_buffers &ext, const std::vector<dn_matrix<r_t>> &gathered,
                       const r_t alpha, const r_t beta, const std::string name = "", const uint32_t last_flags = 0) {
     const auto P = ctx.size();
     const int cs = ctx.bcast_stream_id();
+    const auto &cb = A.chunk_bounds();
+    const std::size_t K = A.chunks(), d = B.m();
     ctx.record(name + "0_matmul-spmm", 0);
-    ctx.wait(name + "0_matmul-spmm", 1);
+    ctx.wait(name + "0_matmul-spmm", cs);                 // the comm stream sees the producer of B (and the
+                                                          // previous call's readers of `gathered`)
     ctx.record(name + "0_matmul-bcast-start", cs);
-    if (P > 1) B.allgather(ctx, gathered, cs);
+    for (std::size_t c = 0; c < K; c++) {                 // all K pieces are queued at once and land in order
+        B.allgather(ctx, gathered, cb[c], cb[c + 1], cs);
+        ctx.record(name + std::to_string(c) + "_matmul-bcast-finish", cs);
+    }
+    for (std::size_t j = 0; j < P; j++)                   // local block: no dependency on the exchange
+        matmul(ctx[j], A[{j, j}], B[j], C[j], ext.block[j][j], alpha, beta, P == 1 ? last_flags : 0u);
+    for (std::size_t c = 0; c < K; c++) {
+        ctx.wait(name + std::to_string(c) + "_matmul-bcast-finish", 0);
+        if (P == 1) continue;
+        const std::size_t len = cb[c + 1] - cb[c];
+        for (std::size_t j = 0; j < P; j++) {
+            const dn_matrix<r_t> piece(P * len, d, mggcn::device_view(gathered[j].shared_buffer(), P * cb[c] * d));
+            matmul(ctx[j], A.remote_chunk(j, c), piece, C[j], ext.piece[j][c], alpha, (r_t)1, c + 1 == K ? last_flags : 0u);
+        }
+    }
+    ctx.record(name + "1_matmul-spmm", 0);
+    ctx.register_timer(name + "matmul-spmm", name + "0_matmul-spmm", name + "1_matmul-spmm");
+}
+
+// Halo schedule: what each GPU sends is fixed by the partition, so the index lists live with the caller
+// (dist_halo_plan, built once per matrix); recv[j] holds [need(j,0) | need(j,1) | ...] rows of width d.
+template <typename r_t>
+struct dist_halo_plan {
+    std::vector<mggcn::device_ptr<std::uint32_t>> send_idx;   // [j]: rows of shard j to pack, destination order
+    std::vector<std::size_t> send_rows, recv_rows;            // [j]
+    std::vector<std::size_t> rows;                            // [j*P + k]: rows GPU j sends to GPU k
+    std::vector<mggcn::device_ptr<r_t>> send_buf;             // [j], grown on demand
+    std::size_t send_width = 0;
+
+    dist_halo_plan() = default;
+    template <typename x_t, typename v_t>
+    dist_halo_plan(const dist_context &ctx, const dist_row_csr_matrix<x_t, v_t, r_t> &A) {
+        const auto P = ctx.size();
+        rows.assign(P * P, 0);
+        send_rows.assign(P, 0);
+        recv_rows.assign(P, 0);
+        for (std::size_t j = 0; j < P; j++) {
+            std::vector<std::uint32_t> idx;
+            for (std::size_t k = 0; k < P; k++) {
+                const auto &nd = A.halo_need(k, j);           // rows of shard j that GPU k needs
+                rows[j * P + k] = nd.size();
+                idx.insert(idx.end(), nd.begin(), nd.end());
+                recv_rows[k] += nd.size();
+            }
+            send_rows[j] = idx.size();
+            ctx[j].set();
+            send_idx.push_back(mggcn::device_malloc<std::uint32_t>(std::max<std::size_t>(idx.size(), 1)));
+            if (!idx.empty()) mggcn::upload(send_idx.back().get(), idx.data(), idx.size());
+        }
+        send_buf.resize(P);
+    }
+    void reserve(const dist_context &ctx, std::size_t d) {
+        if (d <= send_width) return;
+        ctx.sync();
+        for (std::size_t j = 0; j < ctx.size(); j++) {
+            ctx[j].set();
+            send_buf[j] = mggcn::device_malloc<r_t>(std::max<std::size_t>(send_rows[j], 1) * d);
+        }
+        send_width = d;
+    }
+};
+
+template <typename x_t, typename v_t, typename r_t>
+void matmul_halo(dist_context ctx, dist_row_csr_matrix<x_t, v_t, r_t> A, dist_row_dn_matrix<r_t> B, dist_row_dn_matrix<r_t> C,
+                 const dist_spmm_buffers &ext, dist_halo_plan<r_t> &halo, const std::vector<dn_matrix<r_t>> &recv,
+                 const r_t alpha, const r_t beta, const std::string name = "", const uint32_t last_flags = 0) {
+    const auto P = ctx.size();
+    const int cs = ctx.bcast_stream_id();
+    const std::size_t d = B.m();
+    halo.reserve(ctx, d);
+    ctx.record(name + "0_matmul-spmm", 0);
+    for (std::size_t j = 0; j < P; j++) {                 // pack on the compute stream
+        ctx[j].set();
+        if (halo.send_rows[j])
+            mggcn_gather_rows_f32(ctx[j].stream(0), B[j].buffer(), d, halo.send_idx[j].get(), halo.send_rows[j], (uint32_t)d,
+                                  halo.send_buf[j].get(), d);
+    }
+    ctx.record(name + "0_matmul-halo-packed", 0);
+    ctx.wait(name + "0_matmul-halo-packed", cs);
+    ctx.record(name + "0_matmul-bcast-start", cs);
+    {
+        std::vector<const float *> send;
+        std::vector<float *> rcv;
+        std::vector<std::size_t> counts(P * P);
+        for (std::size_t j = 0; j < P; j++) { send.push_back(halo.send_buf[j].get()); rcv.push_back(recv[j].buffer()); }
+        for (std::size_t q = 0; q < P * P; q++) counts[q] = halo.rows[q] * d;
+        const auto streams = ctx.streams(cs);
+        mggcn_comm_alltoallv_f32(ctx.comm(), send.data(), rcv.data(), counts.data(), streams.data());
+    }
     ctx.record(name + "0_matmul-bcast-finish", cs);
     for (std::size_t j = 0; j < P; j++)
         matmul(ctx[j], A[{j, j}], B[j], C[j], ext.block[j][j], alpha, beta, P == 1 ? last_flags : 0u);
-    if (P > 1) {
-        ctx.wait(name + "0_matmul-bcast-finish", 0);
-        for (std::size_t j = 0; j < P; j++)
-            matmul(ctx[j], A.remote(j), gathered[j], C[j], ext.remote[j], alpha, (r_t)1, last_flags);
-    }
+    ctx.wait(name + "0_matmul-bcast-finish", 0);
+    if (P > 1)
+        for (std::size_t j = 0; j < P; j++) {
+            const dn_matrix<r_t> r(std::max<std::size_t>(halo.recv_rows[j], 1), d, recv[j].shared_buffer());
+            matmul(ctx[j], A.halo_remote(j), r, C[j], ext.halo[j], alpha, (r_t)1, last_flags);
+        }
     ctx.record(name + "1_matmul-spmm", 0);
     ctx.register_timer(name + "matmul-spmm", name + "0_matmul-spmm", name + "1_matmul-spmm");
 }

@@ -204,6 +204,7 @@ class csr_matrix:
         self.M_ = int(M if M is not None else self.N_)
         assert self.indices.shape[0] == self.nnz() and self.data.shape[0] == self.nnz()
         self._dev = None
+        self._version = 0
 
     def n(self) -> int: return self.N_
     def m(self) -> int: return self.M_
@@ -218,7 +219,15 @@ class csr_matrix:
     def normalize(self, axis: bool = False) -> None:
         _lib.load().mggcn_csr_normalize_host(self.N_, self.M_, self.indptr.ctypes.data,
                                              self.indices.ctypes.data, self.data.ctypes.data, int(bool(axis)))
+        self.invalidate()
+
+    def invalidate(self) -> None:
+        """Call after editing ``indptr`` / ``indices`` / ``data`` in place: drops the device copy AND the
+        SpMM plans cached on this matrix (ops.spmm_plan_for) -- a sweep plan carries its own copy of the
+        values, so a stale plan would silently multiply with the old matrix."""
         self._dev = None
+        self._version = getattr(self, "_version", 0) + 1
+        self.__dict__.pop("_spmm_plans", None)
 
     def transpose(self) -> "csr_matrix":
         nnz = self.nnz()

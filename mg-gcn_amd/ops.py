@@ -26,6 +26,8 @@ class spmm_buffer:
     def __init__(self, lib, handle: int):
         self.lib, self.handle = lib, handle
         self.max_d = 0
+        self.d_hint = 0
+        self.version = 0            # csr_matrix._version the plan was built from
 
     def num_items(self) -> int: return self.lib.mggcn_spmm_plan_num_items(self.handle)
     def num_split_rows(self) -> int: return self.lib.mggcn_spmm_plan_num_split_rows(self.handle)
@@ -63,7 +65,7 @@ def spmm_plan_for(ctx: context, A: csr_matrix, max_d: int, d_hint: int) -> spmm_
         h = ctx.lib.mggcn_spmm_plan_create_for(A.n(), A.m(), A.indptr.ctypes.data, A.indices.ctypes.data,
                                                A.data.ctypes.data, int(max_d), int(d_hint))
         buf = cache[key] = spmm_buffer(ctx.lib, h)
-        buf.max_d = int(max_d)
+        buf.max_d, buf.d_hint, buf.version = int(max_d), int(d_hint), A._version
     return buf
 
 
@@ -80,6 +82,10 @@ def _spmm(ctx: context, A: csr_matrix, B: dn_matrix, C: dn_matrix, ext_buffer: O
           alpha: float, beta: float, flags: int = 0, slope: float = 0.01, stream_id: int = 0) -> None:
     _req(A.m() == B.n() and B.m() == C.m() and A.n() == C.n(), "SpMM shape mismatch")
     ctx.set()
+    if ext_buffer is not None and ext_buffer.version != A._version:
+        # the matrix was edited in place after the plan was built (csr_matrix.normalize / invalidate): the
+        # reference's cuSPARSE workspace holds no values, so the same call sequence must keep working
+        ext_buffer = spmm_plan_for(ctx, A, ext_buffer.max_d, ext_buffer.d_hint or B.m())
     ip, ix, dv = A.device(ctx.device)
     ctx.lib.mggcn_spmm_csr_f32(ctx.stream(stream_id), ext_buffer.handle if ext_buffer else None, A.n(), A.m(),
                                ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), B.buffer(), B.m(), C.buffer(),
@@ -112,6 +118,24 @@ def linear_forward(ctx: context, X: dn_matrix, W: dn_matrix, b: dn_matrix, XW: d
     ws = ctx.workspace(ws_bytes)
     ctx.lib.mggcn_gemm_bias_f32(ctx.stream(0), 0, 0, X.n(), W.m(), X.m(), 1.0, X.buffer(), X.m(), W.buffer(), W.m(),
                                 b.buffer(), XW.buffer(), XW.m(), ws.data_ptr() if ws is not None else None, ws_bytes)
+
+
+def matmul_lrelu_backward(ctx: context, A: dn_matrix, B: dn_matrix, Z: dn_matrix, C: dn_matrix, alpha: float = 1.0,
+                          A_T: bool = False, B_T: bool = False, slope: float = 0.01) -> None:
+    """C = (alpha op(A) op(B)) .* (Z > 0 ? 1 : slope): the GEMM that produces a layer's input gradient with the
+    leaky_relu_backward of the layer below folded into its epilogue (src/gcn.hpp:135-137 + :462-468)."""
+    A_n, A_m, B_n, B_m = A.n(), A.m(), B.n(), B.m()
+    if A_T:
+        A_n, A_m = A_m, A_n
+    if B_T:
+        B_n, B_m = B_m, B_n
+    _req(A_m == B_n and A_n == C.n() and B_m == C.m() and Z.shape() == C.shape(), "GEMM + mask shape mismatch")
+    ctx.set()
+    ws_bytes = ctx.lib.mggcn_gemm_workspace_bytes(int(A_T), int(B_T), A_n, B_m, A_m)
+    ws = ctx.workspace(ws_bytes)
+    ctx.lib.mggcn_gemm_lrelu_bwd_f32(ctx.stream(0), int(A_T), int(B_T), A_n, B_m, A_m, alpha, A.buffer(), A.m(),
+                                     B.buffer(), B.m(), Z.buffer(), Z.m(), slope, C.buffer(), C.m(),
+                                     ws.data_ptr() if ws is not None else None, ws_bytes)
 
 
 def gather_rows(ctx: context, src: dn_matrix, indices, dst: dn_matrix, stream_id: int = 0) -> None:
@@ -221,3 +245,29 @@ def adam_fused(ctx: context, param: dn_matrix, grad: dn_matrix, m: dn_matrix, v:
     _req(param.shape() == grad.shape() == m.shape() == v.shape(), "shape mismatch")
     ctx.lib.mggcn_adam_fused_f32(ctx.stream(0), param.buffer(), grad.buffer(), m.buffer(), v.buffer(), lr,
                                  beta1, beta2, weight_decay, c1, c2, eps, param.size())
+
+
+class adam_table:
+    """Device table of every (param, grad, m, v) quadruple of a model for mggcn_adam_multi_f32: built once
+    (the buffers of a model never move), one launch per epoch instead of two per layer."""
+
+    def __init__(self, ctx: context, tensors) -> None:
+        """tensors: [(param, grad, m, v, weight_decay_on)] of dn_matrix"""
+        import numpy as np
+        torch = __import__("torch")
+        dt = np.dtype([("param", "<u8"), ("grad", "<u8"), ("m", "<u8"), ("v", "<u8"), ("size", "<u8"),
+                       ("wd", "<f4"), ("first_block", "<u4")])
+        assert dt.itemsize == 48
+        tab = np.zeros(len(tensors), dtype=dt)
+        blocks = 0
+        for k, (p, g, m, v, wd) in enumerate(tensors):
+            _req(p.shape() == g.shape() == m.shape() == v.shape(), "shape mismatch")
+            tab[k] = (p.buffer(), g.buffer(), m.buffer(), v.buffer(), p.size(), wd, blocks)
+            blocks += ctx.lib.mggcn_adam_multi_blocks(p.size())
+        self.n, self.blocks = len(tensors), blocks
+        self.keep = tensors                                       # the table holds raw pointers
+        self.dev = torch.from_numpy(tab.view(np.uint8).copy()).to(ctx.device)
+        torch.cuda.current_stream(self.dev.device).synchronize()
+
+    def step(self, ctx: context, lr: float, beta1: float, beta2: float, c1: float, c2: float, eps: float) -> None:
+        ctx.lib.mggcn_adam_multi_f32(ctx.stream(0), self.dev.data_ptr(), self.n, self.blocks, lr, beta1, beta2, c1, c2, eps)

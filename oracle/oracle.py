@@ -247,7 +247,7 @@ def leaky_relu_backward(act: np.ndarray, G: np.ndarray, alpha: float = 0.01) -> 
     return out
 
 
-def softmax_rows(H: np.ndarray) -> np.ndarray:
+def softmax_rows(H: np.ndarray, f64acc: bool = False) -> np.ndarray:
     """softmax::operator() -- src/gcn.hpp:651-675: max_rows, subtract_rows_exp,
     row sums by a GEMM with a ones vector, scale_rows."""
     H = np.ascontiguousarray(H, dtype=np.float32)
@@ -256,18 +256,18 @@ def softmax_rows(H: np.ndarray) -> np.ndarray:
     lib().orc_max_rows(_ptr(H, f32p), _ptr(maxs, f32p), H.size, m)
     E = np.empty_like(H)
     lib().orc_subtract_rows_exp(_ptr(H, f32p), _ptr(maxs, f32p), _ptr(E, f32p), H.size, m)
-    R = gemm(E, np.ones((m, 1), dtype=np.float32))
+    R = gemm(E, np.ones((m, 1), dtype=np.float32), f64acc=f64acc)
     lib().orc_scale_rows(_ptr(E, f32p), _ptr(R, f32p), E.size, m)
     return E
 
 
-def softmax_cross_entropy(H: np.ndarray, Y: np.ndarray, n_global: Optional[int] = None
-                          ) -> Tuple[float, float, np.ndarray, np.ndarray]:
+def softmax_cross_entropy(H: np.ndarray, Y: np.ndarray, n_global: Optional[int] = None,
+                          f64acc: bool = False) -> Tuple[float, float, np.ndarray, np.ndarray]:
     """softmax_cross_entropy_loss::operator() -- src/gcn.hpp:785-818.
     Returns (sum|log p_y|, sum[y==argmax], G = (O - onehot)/n_global, O).
     The caller divides the two sums by n (src/gcn.hpp:817 / :929)."""
     Y = np.ascontiguousarray(Y, dtype=np.int32).reshape(-1)
-    O = softmax_rows(H)
+    O = softmax_rows(H, f64acc)
     n, m = O.shape
     if n_global is None:
         n_global = n
@@ -291,7 +291,8 @@ def softmax_cross_entropy(H: np.ndarray, Y: np.ndarray, n_global: Optional[int] 
 class Linear:
     """linear<r_t> -- src/gcn.hpp:88-189."""
 
-    def __init__(self, n_in: int, n_out: int, backward_out: bool = True):
+    def __init__(self, n_in: int, n_out: int, backward_out: bool = True, f64acc: bool = False):
+        self.f64acc = f64acc                               # exact-accumulation twin (see Gcn)
         self.W = init_uniform(n_in, n_out)                 # gcn.hpp:108, matrix.hpp:539
         self.b = init_uniform(1, n_out, gain_b())          # gcn.hpp:109
         self.G_W = np.zeros_like(self.W)
@@ -304,15 +305,15 @@ class Linear:
     def forward(self, X: np.ndarray) -> np.ndarray:        # gcn.hpp:116-123
         XW = np.empty((X.shape[0], self.W.shape[1]), dtype=np.float32)
         lib().orc_broadcast_rows(_ptr(self.b, f32p), _ptr(XW, f32p), XW.size, XW.shape[1], 1)
-        gemm(X, self.W, XW, 1.0, 1.0)
+        gemm(X, self.W, XW, 1.0, 1.0, f64acc=self.f64acc)
         self.X = X
         return XW
 
     def backward(self, G: np.ndarray) -> Optional[np.ndarray]:   # gcn.hpp:125-139
         ones = np.ones((1, G.shape[0]), dtype=np.float32)
-        self.G_b = gemm(ones, G)
-        self.G_W = gemm(self.X, G, A_T=True)
-        return gemm(G, self.W, B_T=True) if self.backward_out else None
+        self.G_b = gemm(ones, G, f64acc=self.f64acc)
+        self.G_W = gemm(self.X, G, A_T=True, f64acc=self.f64acc)
+        return gemm(G, self.W, B_T=True, f64acc=self.f64acc) if self.backward_out else None
 
     def adam_update(self, lr, beta1, beta2, weight_decay, eps):  # gcn.hpp:146-172
         L = lib()
@@ -339,12 +340,18 @@ class GcnLayer:
     B -> A*B so the single-GPU and the P-shard simulations share this class."""
 
     def __init__(self, spmm_fwd, spmm_bwd, n_in: int, n_out: int, activation: bool,
-                 backward_spmm: bool = True):
+                 backward_spmm: bool = True, f64acc: bool = False, residual_layer: bool = False):
         self.spmm_fwd, self.spmm_bwd = spmm_fwd, spmm_bwd
-        self.lin = Linear(n_in, n_out, backward_spmm)      # gcn.hpp:430 (backward_out = backward_spmm)
+        self.lin = Linear(n_in, n_out, backward_spmm, f64acc)   # gcn.hpp:430 (backward_out = backward_spmm)
+        # gcn.hpp:430: res_lin(in == out || !residual_layer ? nullopt : linear(name, in, out, backward_spmm))
+        self.residual_layer = residual_layer
+        self.res_lin = Linear(n_in, n_out, backward_spmm, f64acc) if residual_layer and n_in != n_out else None
         self.gemm_first = n_out <= n_in                    # HW.m()==AHW.m(), gcn.hpp:439
         self.activation = activation
         self.backward_spmm = backward_spmm
+
+    def linears(self):
+        return [self.lin] + ([self.res_lin] if self.res_lin is not None else [])
 
     def forward(self, H: np.ndarray) -> np.ndarray:        # gcn.hpp:437-458
         self.H = H
@@ -356,32 +363,57 @@ class GcnLayer:
             Z = self.lin.forward(HW)
         if self.activation:
             Z = leaky_relu_forward(Z)
+        if self.res_lin is not None:                        # gcn.hpp:453-454: res_lin(ctx, H, AHW, discard = false)
+            R = self.res_lin
+            lib().orc_broadcast_rows(_ptr(R.b, f32p), _ptr(Z, f32p), Z.size, Z.shape[1], 0)      # AHW += b   (gcn.hpp:117)
+            gemm(H, R.W, Z, 1.0, 1.0, f64acc=R.f64acc)                                            # AHW += H.W (gcn.hpp:120)
+            R.X = H
+        elif self.residual_layer:                           # gcn.hpp:455-456: axpy(ctx, H, AHW, 1)
+            lib().orc_axpy(_ptr(np.ascontiguousarray(H), f32p), _ptr(Z, f32p), 1.0, Z.size)
         self.AHW = Z
         return Z
 
     def backward(self, G: np.ndarray) -> Optional[np.ndarray]:   # gcn.hpp:460-489
+        # the sign source of leaky_relu_backward is AHW AFTER the residual add (gcn.hpp:464 reads the buffer
+        # the forward pass left, :453-456) -- restated as the reference does it
         T = leaky_relu_backward(self.AHW, G) if self.activation else G
         if self.gemm_first:
             G_HW = self.spmm_bwd(T) if self.backward_spmm else T
-            return self.lin.backward(G_HW)
-        self.lin.X = self.H                                 # lin.setX(H)
-        G_HW = self.lin.backward(T)
-        if G_HW is None:
-            return None
-        return self.spmm_bwd(G_HW) if self.backward_spmm else G_HW
+            G_out = self.lin.backward(G_HW)
+        else:
+            self.lin.X = self.H                             # lin.setX(H)
+            G_HW = self.lin.backward(T)
+            G_out = None if G_HW is None else (self.spmm_bwd(G_HW) if self.backward_spmm else G_HW)
+        if self.res_lin is not None:                        # gcn.hpp:484-485: res_lin->backward(ctx, G, G_out, false)
+            R = self.res_lin
+            ones = np.ones((1, G.shape[0]), dtype=np.float32)
+            R.G_b = gemm(ones, G, f64acc=R.f64acc)
+            R.G_W = gemm(R.X, G, A_T=True, f64acc=R.f64acc)
+            if R.backward_out and G_out is not None:
+                gemm(G, R.W, G_out, 1.0, 1.0, B_T=True, f64acc=R.f64acc)
+        elif self.residual_layer and G_out is not None:     # gcn.hpp:486-487: axpy(ctx, G, G_out, 1)
+            lib().orc_axpy(_ptr(np.ascontiguousarray(G), f32p), _ptr(G_out, f32p), 1.0, G_out.size)
+        return G_out
 
 
 class Gcn:
     """gcn -- src/gcn.hpp:937-995.  A is normalised by column, A_T = A^T, layers
     get (A_T, A): forward multiplies by A_T, backward by A (gcn.hpp:946-955)."""
 
-    def __init__(self, A: Csr, sizes: Sequence[int]):
+    def __init__(self, A: Csr, sizes: Sequence[int], f64acc: bool = False, residual_layer: bool = False):
+        """``f64acc``: every SpMM / GEMM sum is accumulated in fp64 and rounded to fp32 once (inputs,
+        outputs and all element-wise math stay fp32).  The reference's sums run in cuSPARSE / cuBLAS in
+        an unspecified fp32 order; over K = n = 233 k terms (G_b = 1^T G, G_W = X^T G at the Reddit shape)
+        a sequential fp32 sum is itself ~1e-4 away from the exact one, so full-size parity is judged
+        against this twin (same algorithm, order-free), with the fp32 restatement's own distance to it
+        reported next to the device's."""
         A = A.copy()
         normalize(A, True)
         A_T = transpose(A)
         self.A_fwd, self.A_bwd = A_T, A
-        self.layers = [GcnLayer(lambda B, M=A_T: spmm(M, B), lambda B, M=A: spmm(M, B),
-                                sizes[i - 1], sizes[i], i + 1 < len(sizes), i != 1)
+        self.f64acc = f64acc
+        self.layers = [GcnLayer(lambda B, M=A_T: spmm(M, B, f64acc=f64acc), lambda B, M=A: spmm(M, B, f64acc=f64acc),
+                                sizes[i - 1], sizes[i], i + 1 < len(sizes), i != 1, f64acc, residual_layer)
                        for i in range(1, len(sizes))]
 
     def forward(self, H: np.ndarray) -> np.ndarray:
@@ -391,7 +423,7 @@ class Gcn:
 
     def train_forward(self, X: np.ndarray, Y: np.ndarray) -> Tuple[float, float]:
         H = self.forward(np.ascontiguousarray(X, dtype=np.float32))
-        ls, ac, self.G, self.O = softmax_cross_entropy(H, Y)
+        ls, ac, self.G, self.O = softmax_cross_entropy(H, Y, f64acc=self.f64acc)
         n = np.float32(H.shape[0])
         return float(np.float32(ls) / n), float(np.float32(ac) / n)
 
@@ -402,7 +434,8 @@ class Gcn:
 
     def adam_update(self, lr=1e-2, beta1=0.9, beta2=0.999, weight_decay=5e-4, eps=1e-8) -> None:
         for layer in self.layers:
-            layer.lin.adam_update(lr, beta1, beta2, weight_decay, eps)
+            for lin in layer.linears():                     # gcn.hpp:497-500
+                lin.adam_update(lr, beta1, beta2, weight_decay, eps)
 
 
 # ----------------------------------------------------------------------------
@@ -431,7 +464,7 @@ class DistGcn:
     p[i] = i*n/P, W/b replicated (same seed-99 init on every rank),
     G_W / G_b summed over ranks (all-reduce), loss scaled by the GLOBAL n."""
 
-    def __init__(self, A: Csr, sizes: Sequence[int], P: int):
+    def __init__(self, A: Csr, sizes: Sequence[int], P: int, residual_layer: bool = False):
         sizes = list(sizes)
         sizes[-1] = (sizes[-1] + P - 1) // P * P               # main.cpp:135
         assert A.n % P == 0                                      # dist_matrix.hpp:428
@@ -446,7 +479,8 @@ class DistGcn:
         # layers get (A_T, A): forward uses A_Td, backward Ad (gcn.hpp:1023)
         self.ranks = []
         for _ in range(P):
-            self.ranks.append([GcnLayer(None, None, sizes[i - 1], sizes[i], i + 1 < len(sizes), i != 1)
+            self.ranks.append([GcnLayer(None, None, sizes[i - 1], sizes[i], i + 1 < len(sizes), i != 1,
+                                        residual_layer=residual_layer)
                                for i in range(1, len(sizes))])
 
     def _shard(self, X: np.ndarray) -> List[np.ndarray]:
@@ -469,6 +503,14 @@ class DistGcn:
                 Z = [L[j].lin.forward(HW[j]) for j in range(P)]
             if L[0].activation:
                 Z = [leaky_relu_forward(z) for z in Z]
+            for j in range(P):                                   # residual branch, row-local (gcn.hpp:572-575)
+                if L[j].res_lin is not None:
+                    R = L[j].res_lin
+                    lib().orc_broadcast_rows(_ptr(R.b, f32p), _ptr(Z[j], f32p), Z[j].size, Z[j].shape[1], 0)
+                    gemm(H[j], R.W, Z[j], 1.0, 1.0)
+                    R.X = H[j]
+                elif L[j].residual_layer:
+                    lib().orc_axpy(_ptr(np.ascontiguousarray(H[j]), f32p), _ptr(Z[j], f32p), 1.0, Z[j].size)
             for j in range(P):
                 L[j].AHW = Z[j]
             H = Z
@@ -487,6 +529,7 @@ class DistGcn:
         nl = len(self.ranks[0])
         for li in reversed(range(nl)):
             L = [self.ranks[j][li] for j in range(P)]
+            G_in = G
             T = [leaky_relu_backward(L[j].AHW, G[j]) if L[0].activation else G[j] for j in range(P)]
             if L[0].gemm_first:
                 G_HW = dist_spmm(self.Ad, T) if L[0].backward_spmm else T
@@ -496,14 +539,28 @@ class DistGcn:
                     L[j].lin.X = L[j].H
                 G_HW = [L[j].lin.backward(T[j]) for j in range(P)]
                 G = dist_spmm(self.Ad, G_HW) if L[0].backward_spmm else G_HW
+            Gin = G_in
+            for j in range(P):                                   # residual branch (gcn.hpp:603-606)
+                if L[j].res_lin is not None:
+                    R = L[j].res_lin
+                    R.G_b = gemm(np.ones((1, Gin[j].shape[0]), dtype=np.float32), Gin[j])
+                    R.G_W = gemm(R.X, Gin[j], A_T=True)
+                    if R.backward_out and G[j] is not None:
+                        gemm(Gin[j], R.W, G[j], 1.0, 1.0, B_T=True)
+                elif L[j].residual_layer and G[j] is not None:
+                    lib().orc_axpy(_ptr(np.ascontiguousarray(Gin[j]), f32p), _ptr(G[j], f32p), 1.0, G[j].size)
             # all-reduce(sum) of G_W and G_b over ranks -- gcn.hpp:236-240, cuda_utils.hpp:304-313
-            GW = L[0].lin.G_W.copy(); Gb = L[0].lin.G_b.copy()
-            for j in range(1, P):
-                GW += L[j].lin.G_W; Gb += L[j].lin.G_b
-            for j in range(P):
-                L[j].lin.G_W = GW.copy(); L[j].lin.G_b = Gb.copy()
+            for pick in ((lambda l: l.lin), (lambda l: l.res_lin)):
+                if pick(L[0]) is None:
+                    continue
+                GW = pick(L[0]).G_W.copy(); Gb = pick(L[0]).G_b.copy()
+                for j in range(1, P):
+                    GW += pick(L[j]).G_W; Gb += pick(L[j]).G_b
+                for j in range(P):
+                    pick(L[j]).G_W = GW.copy(); pick(L[j]).G_b = Gb.copy()
 
     def adam_update(self, lr=1e-2, beta1=0.9, beta2=0.999, weight_decay=5e-4, eps=1e-8) -> None:
         for layers in self.ranks:
             for layer in layers:
-                layer.lin.adam_update(lr, beta1, beta2, weight_decay, eps)
+                for lin in layer.linears():
+                    lin.adam_update(lr, beta1, beta2, weight_decay, eps)

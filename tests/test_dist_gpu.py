@@ -30,7 +30,7 @@ def _data(n, F, C):
     return pkg, (ip, ix, dv), X, Y
 
 
-def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo", chunks=None):
+def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo", chunks=None, overlap=True):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":
@@ -42,7 +42,8 @@ def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo", chu
     try:
         pkg, (ip, ix, dv), X, Y = _data(n, F, C)
         D = pkg.dist
-        dctx = D.dist_context(overlap=True, device_index=0)
+        dctx = D.dist_context(overlap=overlap, device_index=0)
+        assert dctx.bcast_stream_id() == (1 if overlap else 0)            # src/dist_matrix.hpp:20-22
         A = pkg.csr_matrix(ip, ix, dv, n)
         A.normalize(True)
         A_T = A.transpose()
@@ -69,14 +70,18 @@ def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo", chu
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("P,mode,chunks", [(2, "allgather", None), (2, "rounds", None), (3, "allgather", None),
-                                           (2, "allgather", 3), (4, "allgather", 2), (2, "halo", None), (3, "halo", None)])
-def test_dist_gcn_matches_oracle(oracle, P, mode, chunks):
+@pytest.mark.parametrize("P,mode,chunks,overlap", [
+    (2, "allgather", None, True), (2, "rounds", None, True), (3, "allgather", None, True), (2, "allgather", 3, True),
+    (4, "allgather", 2, True), (2, "halo", None, True), (3, "halo", None, True),
+    # the reference's -S flag: overlap = false puts the exchange on the compute stream (src/dist_matrix.hpp:20-22,
+    # src/main.cpp:66) -- same results, every schedule
+    (2, "allgather", None, False), (2, "rounds", None, False), (2, "halo", None, False)])
+def test_dist_gcn_matches_oracle(oracle, P, mode, chunks, overlap):
     n, F, C, hidden, epochs = 1536, 20, 5, [16, 16], 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, P, port, n, F, C, hidden, mode, epochs, q, "gloo", chunks))
+    procs = [ctx.Process(target=_worker, args=(r, P, port, n, F, C, hidden, mode, epochs, q, "gloo", chunks, overlap))
              for r in range(P)]
     for pr in procs:
         pr.start()
@@ -105,15 +110,16 @@ def test_dist_gcn_matches_oracle(oracle, P, mode, chunks):
         assert res[r][1][0][0] == res[0][1][0][0]                           # same global loss on every rank
 
 
+@pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("mode", ["allgather", "rounds", "halo"])
-def test_dist_gcn_over_rccl_single_rank(oracle, mode):
+def test_dist_gcn_over_rccl_single_rank(oracle, mode, overlap):
     """The RCCL transport itself (backend "nccl": all_gather_into_tensor / broadcast / all_reduce on
     the comm stream, stream-level waits) with the one rank a one-GPU box allows; the multi-rank
     logic above it is what the gloo cases check."""
     n, F, C, hidden, epochs = 1536, 20, 5, [16, 16], 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    pr = ctx.Process(target=_worker, args=(0, 1, _free_port(), n, F, C, hidden, mode, epochs, q, "nccl", 2))
+    pr = ctx.Process(target=_worker, args=(0, 1, _free_port(), n, F, C, hidden, mode, epochs, q, "nccl", 2, overlap))
     pr.start()
     rank, out, W = q.get(timeout=300)
     pr.join(timeout=60)

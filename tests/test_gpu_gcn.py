@@ -297,3 +297,43 @@ def test_train_step_equals_the_three_calls(pkg, ctx):
     for a, b in zip(Ga.layers(), Gb.layers()):
         np.testing.assert_array_equal(a.W().numpy(), b.W().numpy())
         np.testing.assert_array_equal(a.b().numpy(), b.b().numpy())
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("sizes", [[16, 16, 16, 5], [24, 16, 32, 16, 6]])
+def test_residual_layer_matches_oracle(pkg, oracle, ctx, fused, sizes):
+    """gcn(A, sizes, residual_layer = true): res_lin when the widths differ, a plain add otherwise, the loss on
+    a copy of the logits (src/gcn.hpp:418, :430, :453-456, :484-487, :946).  The reference CLI never enables it
+    and no reference test covers it: parity unpinned by the reference, pinned against the oracle's restatement
+    of those lines.  [24, 16, 32, 16, 6] exercises res_lin on GEMM-first and SpMM-first layers and the first
+    layer's skipped input gradient."""
+    n = 1536
+    ip, ix, dv = _graph(pkg, n, n * 20, 900, seed=sizes[0] + len(sizes))
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((n, sizes[0]), dtype=np.float32)
+    Y = rng.integers(0, sizes[-1], size=(n, 1)).astype(np.int32)
+    G = pkg.gcn(pkg.csr_matrix(ip, ix, dv, n), sizes, residual_layer=True, fused=fused)
+    O = oracle.Gcn(oracle.Csr(ip, ix, dv, n), sizes, residual_layer=True)
+    assert [l.res_lin is not None for l in G.layers()] == [a != b for a, b in zip(sizes[:-1], sizes[1:])]
+    Xd, Yd = pkg.dn_matrix.from_numpy(X), pkg.dn_matrix.from_numpy(Y)
+    for epoch in range(2):
+        for layer, ol in zip(G.layers(), O.layers):                       # identical state at the start of the epoch
+            for lin, olin in zip(layer.linears(), ol.linears()):
+                olin.W, olin.b = lin.W.numpy().copy(), lin.b.numpy().copy()
+                if lin.mW is not None:
+                    olin.mW, olin.vW, olin.mb, olin.vb = (t.numpy().copy() for t in (lin.mW, lin.vW, lin.mb, lin.vb))
+                    olin.step = lin.step
+        loss, acc = G.train_forward(ctx, Xd, Yd)
+        G.backward(ctx)
+        ctx.sync()
+        ol_, oa_ = O.train_forward(X, Y)
+        O.backward()
+        assert abs(loss - ol_) <= TOL * abs(ol_), (epoch, loss, ol_)
+        assert abs(acc - oa_) <= 3.0 / n
+        for li, (layer, olayer) in enumerate(zip(G.layers(), O.layers)):
+            for k, (lin, olin) in enumerate(zip(layer.linears(), olayer.linears())):
+                assert relerr(lin.G_W.numpy(), olin.G_W) <= TOL, (epoch, li, k, "G_W")
+                assert relerr(lin.G_b.numpy(), olin.G_b) <= TOL, (epoch, li, k, "G_b")
+        G.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+        O.adam_update()
+        ctx.sync()

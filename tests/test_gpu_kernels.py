@@ -356,6 +356,34 @@ def test_sweep_equals_rowsplit_on_a_big_graph(pkg, ctx, monkeypatch):
     assert rowwise_relerr(s, r) <= 2e-5
 
 
+def test_plan_follows_in_place_edits_of_the_matrix(pkg, oracle, ctx, monkeypatch):
+    """SpMM, normalize(True), SpMM with the SAME ext_buffer: a sweep plan carries its own copy of the
+    values, the reference's cuSPARSE workspace does not (src/cuda_utils.hpp:94-102) -- the call sequence
+    must multiply with the edited matrix both through a fresh get_matmul_buffer and through the old handle."""
+    monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
+    n, d = 40_000, 128
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 3_000_000, 9000, seed=14)
+    dv = np.random.default_rng(14).random(dv.shape[0], dtype=np.float32) + 0.5
+    A, Ao = _csr(pkg, oracle, ip, ix, dv.copy(), n)
+    B = np.random.default_rng(15).standard_normal((n, d), dtype=np.float32)
+    Bd, Cd = pkg.dn_matrix.from_numpy(B), pkg.dn_matrix(n, d)
+    buf = pkg.get_matmul_buffer(ctx, A, Bd, Cd)
+    assert buf.num_sweep_tasks() > 0
+    pkg.matmul(ctx, A, Bd, Cd, buf, 1.0, 0.0); ctx.sync()
+    assert rowwise_relerr(Cd.numpy(), oracle.spmm(Ao, B, f64acc=True)) <= TOL
+    A.normalize(True); oracle.normalize(Ao, True)
+    want = oracle.spmm(Ao, B, f64acc=True)
+    pkg.matmul(ctx, A, Bd, Cd, buf, 1.0, 0.0); ctx.sync()                 # stale handle: re-planned inside
+    assert rowwise_relerr(Cd.numpy(), want) <= TOL
+    buf2 = pkg.get_matmul_buffer(ctx, A, Bd, Cd)
+    assert buf2 is not buf and buf2.version == A._version
+    pkg.matmul(ctx, A, Bd, Cd, buf2, 1.0, 0.0); ctx.sync()
+    assert rowwise_relerr(Cd.numpy(), want) <= TOL
+    A.data *= np.float32(2.0); A.invalidate()                             # any other in-place edit
+    pkg.matmul(ctx, A, Bd, Cd, buf2, 1.0, 0.0); ctx.sync()
+    assert rowwise_relerr(Cd.numpy(), 2 * want.astype(np.float64)) <= TOL
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 608), (777, 41, 128), (130, 48, 7), (5, 128, 9000)])
 def test_gemm_bias_epilogue_equals_broadcast_then_gemm(pkg, oracle, ctx, M, N, K):
     """mggcn_gemm_bias_f32 = broadcast_rows + sgemm(beta = 1) of the reference's linear forward
@@ -412,3 +440,56 @@ def test_gather_rows_packs_the_halo(pkg, ctx, d):
     ctx.sync()
     np.testing.assert_array_equal(D.numpy(), src[idx])
     pkg.ops.gather_rows(ctx, S, dev_idx[:0], D)          # empty list: no-op
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 128), (2049, 128, 41), (300, 608, 128), (70, 48, 9000)])
+def test_gemm_lrelu_backward_epilogue_equals_gemm_then_kernel(pkg, oracle, ctx, M, N, K):
+    """mggcn_gemm_lrelu_bwd_f32 (G_out = (G . W^T) .* leaky_relu'(Z), src/gcn.hpp:135-137 + :462-468) is
+    BITWISE the two launches it replaces (sgemm with beta = 0, then leaky_relu_backward_kernel), incl. the
+    split-K path (K = 9000), and matches the oracle."""
+    rng = np.random.default_rng(M + N + K)
+    G = rng.standard_normal((M, K), dtype=np.float32)
+    W = rng.standard_normal((N, K), dtype=np.float32)          # used transposed: G . W^T
+    Z = rng.standard_normal((M, N), dtype=np.float32)
+    Z[0, :4] = 0.0                                             # in > 0 is strict: zeros take the slope
+    Gd, Wd, Zd = (pkg.dn_matrix.from_numpy(a) for a in (G, W, Z))
+    fused = pkg.dn_matrix(M, N); ctx.fill(fused, float("nan"))
+    pkg.ops.matmul_lrelu_backward(ctx, Gd, Wd, Zd, fused, 1.0, False, True)
+    two = pkg.dn_matrix(M, N)
+    pkg.matmul(ctx, Gd, Wd, two, 1.0, 0.0, False, True)
+    pkg.ops.leaky_relu_backward(ctx, Zd, two, two)
+    ctx.sync()
+    np.testing.assert_array_equal(fused.numpy(), two.numpy())
+    want = oracle.leaky_relu_backward(Z, oracle.gemm(G, W, B_T=True, f64acc=True))
+    assert relerr(fused.numpy(), want) <= TOL
+    np.testing.assert_array_equal(Zd.numpy(), Z)               # the mask operand is only read
+
+
+def test_adam_multi_equals_per_tensor_fused(pkg, ctx):
+    """mggcn_adam_multi_f32: one launch over a device table of all parameter tensors == mggcn_adam_fused_f32
+    per tensor, bitwise, over several steps (sizes straddle the 1024-element blocks; biases take no decay)."""
+    rng = np.random.default_rng(77)
+    shapes = [(608, 128), (1, 128), (128, 128), (1, 128), (128, 41), (1, 41), (3, 1), (1025, 1)]
+    mk = lambda a: pkg.dn_matrix.from_numpy(a.copy())
+    P0 = [rng.standard_normal(s, dtype=np.float32) for s in shapes]
+    sets = []
+    for _ in range(2):
+        sets.append([(mk(p), pkg.dn_matrix(*s), pkg.dn_matrix(*s), pkg.dn_matrix(*s)) for p, s in zip(P0, shapes)])
+        for p, g, m, v in sets[-1]:
+            m.zero(ctx); v.zero(ctx)
+    wds = [5e-4 if s[0] > 1 else 0.0 for s in shapes]
+    table = pkg.ops.adam_table(ctx, [(p, g, m, v, wd) for (p, g, m, v), wd in zip(sets[0], wds)])
+    assert table.blocks == sum((s[0] * s[1] + 1023) // 1024 for s in shapes)
+    for step in range(1, 4):
+        bc1, bc2 = float(np.float32(1 - 0.9 ** step)), float(np.float32(1 - 0.999 ** step))
+        grads = [rng.standard_normal(s, dtype=np.float32) for s in shapes]
+        for k, gr in enumerate(grads):
+            for st in sets:
+                st[k][1].init(gr)
+        table.step(ctx, 1e-2, 0.9, 0.999, bc1, bc2, 1e-8)
+        for (p, g, m, v), wd in zip(sets[1], wds):
+            pkg.ops.adam_fused(ctx, p, g, m, v, 1e-2, 0.9, 0.999, wd, bc1, bc2, 1e-8)
+        ctx.sync()
+        for a, b in zip(sets[0], sets[1]):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x.numpy(), y.numpy())
