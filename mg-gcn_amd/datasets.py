@@ -204,7 +204,151 @@ def synth_reddit_like(scale: float = 1.0, seed: int = 1):
 # test/data/prep.py does to a graph before writing it (serialize_dgl_graph :100-126 and
 # serialize_dataset :78-99), on plain numpy / scipy inputs.
 # ----------------------------------------------------------------------------
-def prepare_dataset(dirname: str, adj, features, labels, sets=None, P: int = 8, seed: int = 0) -> str:
+def read_csr_rows(path: str, row_begin: int, row_end: int):
+    """Rows [row_begin, row_end) of a graph.bin WITHOUT reading the rest: header, the indptr slice, then one
+    seek per array (the reference loads the whole file once per process, src/main.cpp:82; with one process per
+    GPU that would be P whole copies on one host).  Returns (indptr u32[rows+1] re-based to 0, indices, data,
+    n_rows_total, n_cols)."""
+    if not str(path).endswith(".bin"):
+        raise format_error("File type is not supported.")
+    with open(path, "rb") as f:
+        head = f.read(13)
+        if len(head) != 13 or head[:11] != MAGIC or head[11] != 4 or head[12] != 4:
+            raise format_error(f"{path}: not a 4-byte PIGO-CSR-v2 file")
+        _n, nnz, nrows, ncols = (int(x) for x in np.frombuffer(f.read(16), dtype="<u4"))
+        if not (0 <= row_begin <= row_end <= nrows):
+            raise format_error(f"{path}: rows [{row_begin}, {row_end}) outside 0..{nrows}")
+        base = 13 + 16
+        f.seek(base + 4 * row_begin)
+        ip = np.fromfile(f, dtype="<u4", count=row_end - row_begin + 1)
+        lo, hi = int(ip[0]), int(ip[-1])
+        f.seek(base + 4 * (nrows + 1) + 4 * lo)
+        indices = np.fromfile(f, dtype="<u4", count=hi - lo)
+        f.seek(base + 4 * (nrows + 1) + 4 * nnz + 4 * lo)
+        data = np.fromfile(f, dtype="<f4", count=hi - lo)
+    if ip.shape[0] != row_end - row_begin + 1 or indices.shape[0] != hi - lo or data.shape[0] != hi - lo:
+        raise format_error(f"{path}: truncated payload")
+    return (ip - np.uint32(lo)).astype(np.uint32), indices, data, nrows, ncols
+
+
+def read_dense_rows(path: str, dtype, row_begin: int, row_end: int) -> np.ndarray:
+    """rows [row_begin, row_end) of a dense .bin file (features / labels / sets), one seek"""
+    with open(path, "rb") as f:
+        shape = np.frombuffer(f.read(8), dtype="<u4")
+        n, m = int(shape[0]), int(shape[1])
+        if not (0 <= row_begin <= row_end <= n):
+            raise format_error(f"{path}: rows [{row_begin}, {row_end}) outside 0..{n}")
+        f.seek(8 + np.dtype(dtype).itemsize * m * row_begin)
+        out = np.fromfile(f, dtype=dtype, count=(row_end - row_begin) * m)
+    if out.shape[0] != (row_end - row_begin) * m:
+        raise format_error(f"{path}: truncated payload")
+    return out.reshape(row_end - row_begin, m)
+
+
+def dense_shape(path: str):
+    with open(path, "rb") as f:
+        shape = np.frombuffer(f.read(8), dtype="<u4")
+    return int(shape[0]), int(shape[1])
+
+
+# ----------------------------------------------------------------------------
+# Partitioner hook in front of the 1D row partition (SURVEY.md 8(f) rank 1).  The reference's data-prep script
+# takes a vertex permutation from a file or from PaToH (test/data/prep.py:20, :232-247: `-p <permutation-file>`,
+# `patoh(g, parts, 'RWS')` commented out) and then cuts the permuted graph into contiguous equal blocks
+# p[i] = i*n/P (:253-256).  Same contract here: a partitioner is anything that returns a permutation; the blocks
+# stay contiguous and equal, so the trainer needs no change.
+# ----------------------------------------------------------------------------
+def partition_blocks(adj, P: int, sweeps: int = 10, seed: int = 0) -> np.ndarray:
+    """In-repo partitioner: P equal blocks by breadth-first growing + balanced label propagation.
+    Returns ``perm`` with new vertex i = old vertex perm[i] (block k = perm[k*n/P:(k+1)*n/P]).
+      1. seeds: breadth-first order from a pseudo-peripheral vertex, cut into P equal chunks;
+      2. refinement sweeps (Kernighan-Lin style): every vertex counts its neighbours per block (one sparse
+         product); for every pair of blocks (a, b) the vertices of a and of b are ranked by the gain of crossing
+         and the best-ranked PAIRS with a positive total gain are SWAPPED -- block sizes never change, so
+         n % P == 0 is preserved exactly (src/dist_matrix.hpp:428).
+    Deterministic for a given seed.  PaToH-quality cuts are not the point: the hook is."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import breadth_first_order
+    if isinstance(adj, tuple):
+        ip, ix, dv = adj
+        n0 = len(ip) - 1
+        adj = sp.csr_matrix((np.ones(len(ix), dtype=np.float32), np.asarray(ix), np.asarray(ip)), shape=(n0, n0))
+    A = sp.csr_matrix(adj)
+    n = A.shape[0]
+    if n % P != 0:
+        raise ValueError(f"n = {n} is not a multiple of P = {P} (pad first: prepare_dataset does)")
+    S = sp.csr_matrix((np.ones(A.nnz, dtype=np.float32), A.indices, A.indptr), shape=A.shape)
+    S = sp.csr_matrix(S + S.T)                          # communication is symmetric: a cut edge costs both sides
+    S.setdiag(0); S.eliminate_zeros()
+    rng = np.random.default_rng(seed)
+    # breadth-first order over all components, from a far vertex of a first sweep
+    seen = np.zeros(n, dtype=bool)
+    order = []
+    start = int(rng.integers(0, n))
+    far = breadth_first_order(S, start, directed=False, return_predecessors=False)[-1]
+    for s0 in [int(far)] + list(range(n)):
+        if seen[s0]:
+            continue
+        comp = breadth_first_order(S, s0, directed=False, return_predecessors=False)
+        comp = comp[~seen[comp]]
+        seen[comp] = True
+        order.append(comp)
+        if seen.all():
+            break
+    order = np.concatenate(order)
+    size = n // P
+    label = np.empty(n, dtype=np.int64)
+    label[order] = np.arange(n) // size
+    for _ in range(max(0, sweeps)):
+        onehot = sp.csr_matrix((np.ones(n, dtype=np.float32), (np.arange(n), label)), shape=(n, P))
+        cnt = np.asarray((S @ onehot).todense())                       # neighbours per block
+        free = np.ones(n, dtype=bool)                                  # one move per vertex per sweep (stale counts)
+        moved = 0
+        for a in range(P):
+            for b in range(a + 1, P):
+                va = np.nonzero((label == a) & free)[0]
+                vb = np.nonzero((label == b) & free)[0]
+                ga = cnt[va, b] - cnt[va, a]                           # gain of a -> b
+                gb = cnt[vb, a] - cnt[vb, b]                           # gain of b -> a
+                oa, ob = np.argsort(-ga, kind="stable"), np.argsort(-gb, kind="stable")
+                m = min(oa.size, ob.size)
+                pair = ga[oa[:m]] + gb[ob[:m]]                         # Kernighan-Lin pair gain (sorted: decreasing)
+                k = int(np.searchsorted(-pair, 0.0, side="left"))      # pairs with a positive total
+                k = min(k, max(1, m // 2))
+                if k == 0 or pair[0] <= 0:
+                    continue
+                sa, sb = va[oa[:k]], vb[ob[:k]]
+                label[sa], label[sb] = b, a
+                free[sa] = free[sb] = False
+                moved += 2 * k
+        if moved == 0:
+            break
+    return np.argsort(label, kind="stable").astype(np.int64)
+
+
+def read_permutation_file(path: str) -> np.ndarray:
+    """whitespace-separated vertex ids, the format test/data/prep.py:241-243 reads"""
+    with open(path) as f:
+        return np.array([int(t) for t in f.read().split()], dtype=np.int64)
+
+
+def comm_volume_matrix(indptr, indices, P: int) -> np.ndarray:
+    """L[i, j] = distinct columns of block j referenced by the rows of block i -- exactly the matrix
+    test/data/prep.py:258-266 prints (diagonal included, as there)."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    n = indptr.shape[0] - 1
+    p = [i * n // P for i in range(P + 1)]
+    L = np.zeros((P, P), dtype=np.int64)
+    for i in range(P):
+        mask = np.zeros(n, dtype=bool)
+        mask[np.asarray(indices[indptr[p[i]]:indptr[p[i + 1]]], dtype=np.int64)] = True
+        for j in range(P):
+            L[i, j] = int(mask[p[j]:p[j + 1]].sum())
+    return L
+
+
+def prepare_dataset(dirname: str, adj, features, labels, sets=None, P: int = 8, seed: int = 0,
+                    permutation=None, partitioner=None) -> str:
     """adj: scipy sparse (n x n) or (indptr, indices, data) CSR triple; features [n x F];
     labels [n]; sets [n] in {0 train, 1 val, 2 test}.
       * pads the vertex count and the feature width to multiples of P with zero vertices /
@@ -212,6 +356,10 @@ def prepare_dataset(dirname: str, adj, features, labels, sets=None, P: int = 8, 
       * adds a self-loop to every vertex, padding included (prep.py:113),
       * seed != 0: applies one random symmetric permutation to graph, features, labels, sets
         and writes under <dirname>/permuted/... like prep.py:80-94,
+      * ``permutation`` (vector over the PADDED vertices, or the path of a permutation file, prep.py:241-243) or
+        ``partitioner`` ("blocks" = partition_blocks, or a callable (adj, P) -> permutation): the partitioner
+        hook -- the permuted graph is written under <dirname>/partitioned/...; its contiguous blocks
+        p[i] = i*n/P are the parts,
       * writes graph.bin / features.bin / labels.bin / sets.bin.  Returns the directory."""
     import scipy.sparse as sp
     if isinstance(adj, tuple):
@@ -234,10 +382,24 @@ def prepare_dataset(dirname: str, adj, features, labels, sets=None, P: int = 8, 
     labs = np.zeros(n, dtype=np.int64); labs[:n0] = labels
     st = np.zeros(n, dtype=np.int64); st[:n0] = sets
     out = dirname
-    if seed != 0:
-        head, tail = os.path.split(os.path.normpath(dirname))
+    perm = None
+    head, tail = os.path.split(os.path.normpath(dirname))
+    if permutation is not None or partitioner is not None:
+        if permutation is not None:
+            perm = read_permutation_file(permutation) if isinstance(permutation, (str, os.PathLike)) else np.asarray(permutation, dtype=np.int64)
+        elif callable(partitioner):
+            perm = np.asarray(partitioner(adj, P), dtype=np.int64)
+        elif partitioner == "blocks":
+            perm = partition_blocks(adj, P, seed=seed)
+        else:
+            raise ValueError(f"unknown partitioner {partitioner!r}")
+        if perm.shape[0] != n or not np.array_equal(np.sort(perm), np.arange(n)):
+            raise ValueError("the permutation must cover the padded vertex set exactly once")
+        out = os.path.join(head, "partitioned", tail)
+    elif seed != 0:
         out = os.path.join(head, "permuted", tail)
         perm = np.random.default_rng(seed).permutation(n)
+    if perm is not None:
         adj = adj[perm][:, perm]
         feats, labs, st = feats[perm], labs[perm], st[perm]
     adj = sp.csr_matrix(adj)

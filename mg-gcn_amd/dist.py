@@ -87,13 +87,17 @@ def split_row_block(A: csr_matrix, row_begin: int, row_end: int, q: Sequence[int
     return [csr_matrix(bip[j].copy(), idx[j], dat[j], int(qa[j + 1] - qa[j])) for j in range(nq)]
 
 
-def split_local_remote(A: csr_matrix, row_begin: int, row_end: int) -> Tuple[csr_matrix, csr_matrix]:
+def split_local_remote(A: csr_matrix, row_begin: int, row_end: int, col_begin: Optional[int] = None,
+                       col_end: Optional[int] = None) -> Tuple[csr_matrix, csr_matrix]:
     """The all-gather form of the same row block: (diagonal block with local column
     indices, everything else with GLOBAL column indices).  Built with the same block
-    splitter: cut at [0, row_begin, row_end, n] and merge the two outer blocks."""
+    splitter: cut at [0, row_begin, row_end, n] and merge the two outer blocks.  ``col_begin/col_end``:
+    the diagonal column range when A is already a ROW BLOCK (rows 0..rows of A = global rows col_begin..)."""
     n = A.m()
-    q = [0, row_begin, row_end, n]
+    cb, ce = (row_begin, row_end) if col_begin is None else (col_begin, col_end)
+    q = [0, cb, ce, n]
     left, diag, right = split_row_block(A, row_begin, row_end, q)
+    row_end_g = ce
     rows = row_end - row_begin
     ln = np.diff(left.indptr.astype(np.int64))
     rn = np.diff(right.indptr.astype(np.int64))
@@ -107,7 +111,7 @@ def split_local_remote(A: csr_matrix, row_begin: int, row_end: int) -> Tuple[csr
     rpos = (np.repeat(indptr[:-1] + ln, rn) + (np.arange(int(rn.sum())) - np.repeat(right.indptr[:-1].astype(np.int64), rn)))
     indices[lpos] = left.indices
     data[lpos] = left.data
-    indices[rpos] = right.indices + np.uint32(row_end)
+    indices[rpos] = right.indices + np.uint32(row_end_g)
     data[rpos] = right.data
     return diag, csr_matrix(indptr.astype(np.uint32), indices, data, n)
 
@@ -231,22 +235,64 @@ def gloo_all_reduce_sum(host_flat, group=None):
 
 
 # --------------------------------------------------------------------------------------
-class dist_context:
-    """reference src/dist_matrix.hpp:12-90, one rank's view.  ``overlap`` selects the
-    comm stream exactly like bcast_stream_id() (:20-22); ``-S`` on the CLI clears it."""
+class host_comm:
+    """Rank / world size + the host-array collectives of the one-off partition step (rank-local load, halo
+    lists).  Needs no GPU with a gloo group (the CPU tests); dist_context is one of these plus the device side."""
 
-    def __init__(self, overlap: bool = True, device_index: Optional[int] = None, group=None):
+    def __init__(self, group=None, device=None):
         dist = _dist()
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised (one process per GPU)")
         self.group = group
         self.P = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.overlap = overlap
         self.backend = dist.get_backend(group)
+        self._comm_device = device                       # nccl moves host arrays through this device
+
+    def _nccl(self) -> bool:
+        return self.backend == "nccl"
+
+    def _to_comm(self, arr: np.ndarray):
+        t = _torch().from_numpy(np.ascontiguousarray(arr))
+        return t.to(self._comm_device) if self._nccl() else t
+
+    def host_all_reduce(self, arr: np.ndarray, op: str = "sum") -> np.ndarray:
+        dist = _dist()
+        t = self._to_comm(arr)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
+        return t.cpu().numpy()
+
+    def host_all_to_all(self, pieces: Sequence[np.ndarray]) -> List[np.ndarray]:
+        """pieces[s] (2-D, same trailing shape and dtype) goes to rank s; returns what every rank sent here,
+        in rank order.  Row counts are exchanged first."""
+        torch, dist = _torch(), _dist()
+        P = self.P
+        width = pieces[0].shape[1:]
+        dt = pieces[0].dtype
+        counts = np.array([int(x.shape[0]) for x in pieces], dtype=np.int64)
+        cin = self._to_comm(counts)
+        cout = torch.empty_like(cin)
+        dist.all_to_all_single(cout, cin, group=self.group)
+        recv_rows = [int(x) for x in cout.cpu().numpy()]
+        send = self._to_comm(np.concatenate([np.ascontiguousarray(x).reshape((-1,) + width) for x in pieces], axis=0))
+        recv = torch.empty((sum(recv_rows),) + tuple(width), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(recv, send, recv_rows, [int(c) for c in counts], group=self.group)
+        out = recv.cpu().numpy().astype(dt, copy=False)
+        offs = np.concatenate([[0], np.cumsum(recv_rows)])
+        return [out[offs[k]:offs[k + 1]] for k in range(P)]
+
+
+class dist_context(host_comm):
+    """reference src/dist_matrix.hpp:12-90, one rank's view.  ``overlap`` selects the
+    comm stream exactly like bcast_stream_id() (:20-22); ``-S`` on the CLI clears it."""
+
+    def __init__(self, overlap: bool = True, device_index: Optional[int] = None, group=None):
+        host_comm.__init__(self, group)
+        self.overlap = overlap
         if device_index is None:
             device_index = self.rank % max(_lib.require_gpu(), 1)
         self.ctx = context(device_index)
+        self._comm_device = self.ctx.device
 
     def size(self) -> int: return self.P
     def bcast_stream_id(self) -> int: return 1 if self.overlap else 0
@@ -260,9 +306,6 @@ class dist_context:
         self.ctx.dump_timers(out, f"{prefix}{self.rank}_")      # "<epoch>_<rank>_<name>:ms"
 
     # -- collectives ------------------------------------------------------------------
-    def _nccl(self) -> bool:
-        return self.backend == "nccl"
-
     def all_gather_rows(self, shard, out, stream_id: int):
         """out[rank*rows:(rank+1)*rows] = shard on every rank.  Returns a handle whose
         .wait(stream_id) orders the result before later work on that stream."""
@@ -409,32 +452,39 @@ class dist_row_csr_matrix:
     all-gather schedule."""
 
     def __init__(self, dctx: dist_context, A: csr_matrix, p: Sequence[int], q: Sequence[int],
-                 chunks: Optional[int] = None):
+                 chunks: Optional[int] = None, row_block: bool = False):
+        """``row_block``: A holds ONLY this rank's rows p[r]..p[r+1] (rank-local load, load_rank_local) instead
+        of the whole matrix; everything below needs no more than that."""
         assert list(p) == list(q), "the reference only ever passes p == q (src/main.cpp:148-149)"
-        self.N_, self.M_ = A.n(), A.m()
+        self.N_, self.M_ = int(p[-1]), A.m()
         self.p = list(p)
         r = dctx.rank
-        self.blocks = split_row_block(A, p[r], p[r + 1], q)               # A[{r, j}]
-        self.diag, self.remote = split_local_remote(A, p[r], p[r + 1])
+        rb, re = (0, p[r + 1] - p[r]) if row_block else (p[r], p[r + 1])
+        assert not row_block or A.n() == re
+        self.blocks = split_row_block(A, rb, re, q)                       # A[{r, j}]
+        self.diag, self.remote = split_local_remote(A, rb, re, p[r], p[r + 1])
         rows = p[r + 1] - p[r]
         K = default_chunks(dctx.P) if chunks is None else int(chunks)
         K = max(1, min(K, rows))
         self.chunk_bounds = chunk_bounds(rows, K)
         self.remote_chunks = split_remote_chunks(self.remote, dctx.P, rows, K)
-        self._full, self._rank, self._P = A, r, dctx.P
+        self._dctx, self._rank, self._P = dctx, r, dctx.P
         self.halo = None
 
     def build_halo(self, device) -> "dist_row_csr_matrix":
-        """Index lists and the renumbered remote block of the halo exchange (mode="halo").  Every rank
-        holds the whole matrix here (it generated or read it), so the lists of what the PEERS need of
-        this rank's shard are computed locally: the distinct columns of block A[{s, r}]."""
+        """Index lists and the renumbered remote block of the halo exchange (mode="halo").  need[s] = rows of
+        shard s this rank's blocks reference (local knowledge); what the PEERS need of this rank's shard comes
+        from ONE all-to-all of those lists -- no rank ever looks at another rank's row block."""
         if self.halo is not None:
             return self
         torch = _torch()
         r, P, p = self._rank, self._P, self.p
         need = halo_need_lists(self.blocks, r)
-        send = [np.unique(split_row_block(self._full, p[s], p[s + 1], p)[r].indices).astype(np.uint32) if s != r
-                else np.empty(0, dtype=np.uint32) for s in range(P)]
+        if P > 1:
+            got = self._dctx.host_all_to_all([x.astype(np.int64).reshape(-1, 1) for x in need])
+            send = [g.reshape(-1).astype(np.uint32) for g in got]
+        else:
+            send = [np.empty(0, dtype=np.uint32)]
         send_idx = np.concatenate(send) if P > 1 else np.empty(0, dtype=np.uint32)
         self.halo = {
             "recv_rows": [int(len(x)) for x in need],
@@ -447,6 +497,72 @@ class dist_row_csr_matrix:
     def n(self): return self.N_
     def m(self): return self.M_
     def __getitem__(self, ij): return self.blocks[ij[1]]
+
+
+def load_rank_local_host(dctx: host_comm, dirname: str):
+    """The dataset as ONE RANK needs it, read without ever holding the whole graph (the reference's single process
+    loads everything once, src/main.cpp:82-85, and splits it for its P GPUs, :143-153; one process per GPU doing the
+    same would hold P whole copies of A, A^T and all P x P blocks on one host -- papers100M: 8 x 40 GB):
+      * rows p[r]..p[r+1] of graph.bin / features.bin / labels.bin through the indptr offsets (datasets.read_csr_rows),
+      * column sums of A by ONE all-reduce of the per-rank partial sums (fp64) -> this rank's rows of the
+        column-normalised A D^-1 (csr_matrix::normalize(true), src/matrix.hpp:340-364),
+      * this rank's rows of (A D^-1)^T by ONE all-to-all: every entry (i, c) goes to the owner of column c, which
+        receives its transposed rows already in increasing source-row order (src/matrix.hpp:392-424),
+      * the class count 1 + max(Y) by a max all-reduce (src/main.cpp:89).
+    Host arrays only (runs without a GPU): returns (A_rows, AT_rows, X, Y, info) -- this rank's rows of the backward
+    and of the forward matrix as csr_matrix with GLOBAL columns."""
+    import os
+    from . import datasets as ds
+    P, r = dctx.P, dctx.rank
+    gpath = os.path.join(dirname, "graph.bin")
+    _, _, _, n, m = ds.read_csr_rows(gpath, 0, 0)
+    if n != m:
+        raise ValueError("graph.bin must be square")
+    p = partition_bounds(n, P)
+    rb, re = p[r], p[r + 1]
+    ip, ix, dv, _, _ = ds.read_csr_rows(gpath, rb, re)
+    # column normalisation: D[c] = sum over ALL rows
+    part = np.bincount(ix.astype(np.int64), weights=dv.astype(np.float64), minlength=n)
+    deg = dctx.host_all_reduce(part).astype(np.float32) if P > 1 else part.astype(np.float32)
+    dvn = (dv / deg[ix.astype(np.int64)]).astype(np.float32)
+    A_rows = csr_matrix(ip, ix, dvn, n)                                     # rows rb..re of A D^-1
+    # transpose by exchange: entry (i, c) -> owner of c as (c - p[owner], i, value)
+    row_g = (np.repeat(np.arange(re - rb, dtype=np.int64), np.diff(ip.astype(np.int64))) + rb)
+    owner = np.searchsorted(np.asarray(p[1:], dtype=np.int64), ix.astype(np.int64), side="right")
+    order = np.argsort(owner, kind="stable")                                # CSR (row-ascending) order kept per owner
+    cuts = np.searchsorted(owner[order], np.arange(P + 1))
+    pieces = []
+    for s_ in range(P):
+        sel = order[cuts[s_]:cuts[s_ + 1]]
+        pieces.append(np.stack([ix[sel].astype(np.int64) - p[s_], row_g[sel], dvn[sel].view(np.int32).astype(np.int64)], axis=1))
+    got = dctx.host_all_to_all(pieces) if P > 1 else pieces
+    ent = np.concatenate(got, axis=0) if got else np.zeros((0, 3), dtype=np.int64)
+    t_order = np.argsort(ent[:, 0], kind="stable")                          # sources arrive in rank = row order
+    t_ip = np.zeros(re - rb + 1, dtype=np.int64)
+    np.cumsum(np.bincount(ent[:, 0], minlength=re - rb), out=t_ip[1:])
+    AT_rows = csr_matrix(t_ip.astype(np.uint32), ent[t_order, 1].astype(np.uint32),
+                         ent[t_order, 2].astype(np.int32).view(np.float32), n)
+    X = ds.read_dense_rows(os.path.join(dirname, "features.bin"), "<f4", rb, re)
+    Y = ds.read_dense_rows(os.path.join(dirname, "labels.bin"), "<i4", rb, re)
+    ymax = int(Y.max()) if Y.size else 0
+    num_labels = 1 + (int(dctx.host_all_reduce(np.array([ymax], dtype=np.int64), "max")[0]) if P > 1 else ymax)
+    info = {"n": n, "nnz_local": int(ip[-1]), "features": int(X.shape[1]), "num_labels": num_labels, "p": p,
+            "host_bytes": int(ip.nbytes + ix.nbytes + 2 * dv.nbytes + ent.nbytes + X.nbytes)}
+    return A_rows, AT_rows, X, Y, info
+
+
+def load_rank_local(dctx: dist_context, dirname: str, chunks: Optional[int] = None):
+    """load_rank_local_host + the device side: (Ad, A_Td, Xd, Yd, info) with Ad / A_Td the backward / forward
+    dist_row_csr_matrix of src/main.cpp:148-149 and Xd / Yd this rank's shard of the features / labels."""
+    A_rows, AT_rows, X, Y, info = load_rank_local_host(dctx, dirname)
+    p, n = info["p"], info["n"]
+    Ad = dist_row_csr_matrix(dctx, A_rows, p, p, chunks, row_block=True)
+    A_Td = dist_row_csr_matrix(dctx, AT_rows, p, p, chunks, row_block=True)
+    Xd = dist_row_dn_matrix.__new__(dist_row_dn_matrix)
+    Xd.N_, Xd.local = n, dn_matrix.from_numpy(X, dctx.ctx.device)
+    Yd = dist_row_dn_matrix.__new__(dist_row_dn_matrix)
+    Yd.N_, Yd.local = n, dn_matrix.from_numpy(Y, dctx.ctx.device)
+    return Ad, A_Td, Xd, Yd, info
 
 
 class dist_sparse_linear:

@@ -193,3 +193,120 @@ def test_halo_volume_follows_the_cut(pkg):
     V2 = D.halo_volume_matrix(pkg.csr_matrix(ip, ix, dv, n), P)
     off = V2[~np.eye(P, dtype=bool)]
     assert (off >= 0.5 * rows).all() and (off <= rows).all() and off.mean() > 4 * V.sum() / 12
+
+
+# ------------------------------------------------------------------------------------------------
+# rank-local load + partitioner hook
+# ------------------------------------------------------------------------------------------------
+def _community_graph(n, P, deg, p_in, seed):
+    """P hidden communities (vertex ids shuffled), `deg` out-edges per vertex, a share p_in of them inside the
+    vertex's own community: the kind of graph a partitioner pays on (the random synthetic Reddit does not)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    comm = rng.permutation(n) % P
+    rows = np.repeat(np.arange(n), deg)
+    same = rng.random(n * deg) < p_in
+    cols = np.empty(n * deg, dtype=np.int64)
+    for k in range(P):
+        idx = np.nonzero((comm[rows] == k) & same)[0]
+        cols[idx] = rng.choice(np.nonzero(comm == k)[0], size=idx.size)
+    idx = np.nonzero(~same)[0]
+    cols[idx] = rng.integers(0, n, size=idx.size)
+    A = sp.csr_matrix((np.ones(n * deg, np.float32), (rows, cols)), shape=(n, n))
+    A.sum_duplicates()
+    A.data[:] = 1.0
+    return A
+
+
+def _rank_local_worker(rank, P, port, dirname, out_q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    D = pkg.dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=P)
+    try:
+        comm = D.host_comm()
+        A_rows, AT_rows, X, Y, info = D.load_rank_local_host(comm, dirname)
+        # what the whole-graph path builds for this rank (src/main.cpp:143-149)
+        (ip, ix, dv, n, _), Xf, Yf, _ = pkg.datasets.read_dataset(dirname)
+        A = pkg.csr_matrix(ip, ix, dv, n)
+        A.normalize(True)
+        A_T = A.transpose()
+        p = D.partition_bounds(n, P)
+        ok = True
+        for got, full in ((A_rows, A), (AT_rows, A_T)):
+            lo, hi = int(full.indptr[p[rank]]), int(full.indptr[p[rank + 1]])
+            ok &= np.array_equal(got.indptr, full.indptr[p[rank]:p[rank + 1] + 1] - full.indptr[p[rank]])
+            ok &= np.array_equal(got.indices, full.indices[lo:hi])
+            ok &= bool(np.allclose(got.data, full.data[lo:hi], rtol=2e-7, atol=0))
+        ok &= np.array_equal(X, Xf[p[rank]:p[rank + 1]]) and np.array_equal(Y, Yf[p[rank]:p[rank + 1]])
+        ok &= info["num_labels"] == 1 + int(Yf.max()) and info["n"] == n
+        # the block matrices built from the row block == built from the whole matrix
+        full_d = D.dist_row_csr_matrix(comm, A_T, p, p, 2)
+        loc_d = D.dist_row_csr_matrix(comm, AT_rows, p, p, 2, row_block=True)
+        for a, b in zip([full_d.diag, full_d.remote] + full_d.blocks + full_d.remote_chunks,
+                        [loc_d.diag, loc_d.remote] + loc_d.blocks + loc_d.remote_chunks):
+            ok &= np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and a.m() == b.m()
+        # halo send lists by exchange == the lists computed from the whole matrix
+        need = D.halo_need_lists(loc_d.blocks, rank)
+        got = comm.host_all_to_all([x.astype(np.int64).reshape(-1, 1) for x in need])
+        for s in range(P):
+            want = np.unique(D.split_row_block(A_T, p[s], p[s + 1], p)[rank].indices) if s != rank else np.empty(0)
+            ok &= np.array_equal(got[s].reshape(-1), want.astype(np.int64))
+        out_q.put((rank, bool(ok), sum(len(x) for x in need), info["host_bytes"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_rank_local_load_and_partitioner_hook(tmp_path, P):
+    """(a) prepare_dataset(partitioner="blocks") on a community graph: the halo volume of the partitioned files is
+    below 50 % of what the all-gather moves ((P-1) n rows) -- and well below the unpartitioned graph's;
+    (b) load_rank_local_host over gloo: every rank reads ONLY its rows of graph.bin / features.bin / labels.bin,
+    normalises by an all-reduce of partial column sums and transposes by one all-to-all, and ends up with exactly
+    the row blocks (and block matrices, and halo send lists) the whole-graph path of src/main.cpp:143-149 builds."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    ds = pkg.datasets
+    n, deg = 2048, 14
+    A = _community_graph(n, P, deg, 0.95, seed=5)
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((n, 10)).astype(np.float32)
+    Y = rng.integers(0, 7, size=n)
+    plain = ds.prepare_dataset(str(tmp_path / "comm"), A, X, Y, P=P)
+    parted = ds.prepare_dataset(str(tmp_path / "comm"), A, X, Y, P=P, partitioner="blocks")
+    assert parted.endswith(os.path.join("partitioned", "comm"))
+    vol = {}
+    for name, d in (("plain", plain), ("parted", parted)):
+        ip, ix, _, nn, _ = ds.read_csr(os.path.join(d, "graph.bin"))
+        L = ds.comm_volume_matrix(ip, ix, P)
+        vol[name] = int(L.sum() - np.trace(L))
+    allgather = (P - 1) * n
+    assert vol["parted"] < 0.5 * allgather and vol["parted"] < 0.6 * vol["plain"], (vol, allgather)
+    # explicit permutation file (the reference's -p <file>, test/data/prep.py:241-243) gives the same files
+    perm = ds.partition_blocks(ds.read_csr(os.path.join(plain, "graph.bin"))[:3], P)
+    pf = tmp_path / "perm.txt"
+    pf.write_text(" ".join(str(int(v)) for v in perm))
+    again = ds.prepare_dataset(str(tmp_path / "again"), A, X, Y, P=P, permutation=str(pf))
+    assert open(os.path.join(again, "graph.bin"), "rb").read() == open(os.path.join(parted, "graph.bin"), "rb").read()
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_local_worker, args=(r, P, port, parted, q)) for r in range(P)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=180) for _ in range(P)])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    import scipy.sparse as sp                                                  # the workers listed the forward matrix A^T
+    ip, ix, dv, nn, _ = ds.read_csr(os.path.join(parted, "graph.bin"))
+    T = sp.csr_matrix(sp.csr_matrix((dv, ix, ip), shape=(nn, nn)).T)
+    LT = ds.comm_volume_matrix(T.indptr, T.indices, P)
+    assert sum(rows for _, _, rows, _ in res) == int(LT.sum() - np.trace(LT))   # halo rows == the comm-volume matrix
+    whole = os.path.getsize(os.path.join(parted, "graph.bin")) + os.path.getsize(os.path.join(parted, "features.bin"))
+    assert max(b for _, _, _, b in res) < 0.9 * whole * 2                       # a rank holds its share, not P copies

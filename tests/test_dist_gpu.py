@@ -133,3 +133,69 @@ def test_dist_gcn_over_rccl_single_rank(oracle, mode, overlap):
     for g, l in zip(grads, O.ranks[0]):
         assert np.abs(g - l.lin.G_W).max() <= 1e-4 * np.abs(l.lin.G_W).max()
     assert np.isfinite(out[-1][0]) and out[-1][0] < out[0][0] * 1.001
+
+
+def _partitioned_worker(rank, P, port, dirname, hidden, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=P)
+    try:
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as ge
+        pkg = ge.load_package()
+        D = pkg.dist
+        dctx = D.dist_context(overlap=True, device_index=0)
+        out = {}
+        for mode in ("halo", "allgather"):
+            Ad, A_Td, Xd, Yd, info = D.load_rank_local(dctx, dirname)           # rank-local: only this rank's rows
+            sizes = [info["features"]] + hidden + [(info["num_labels"] + P - 1) // P * P]
+            G = D.dist_gcn(dctx, Ad, A_Td, sizes, fused=True, mode=mode)
+            loss, acc = G.train_forward(dctx, Xd, Yd)
+            G.backward(dctx)
+            dctx.sync()
+            out[mode] = (loss, acc, [l.GW().local.numpy().copy() for l in G.layers()])
+            if mode == "halo":
+                out["halo_rows"] = sum(A_Td.halo["recv_rows"]) + sum(Ad.halo["recv_rows"])
+        q.put((rank, out, info["n"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_halo_on_a_partitioned_graph_moves_less_and_matches_allgather(pkg, oracle, tmp_path):
+    """The reason mode="halo" exists: on a community graph cut by the in-repo partitioner
+    (datasets.partition_blocks through prepare_dataset's hook) the halo exchange moves well under half of what the
+    all-gather moves, and trains to the same numbers.  Every rank loads only its own rows (dist.load_rank_local)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_dist_cpu import _community_graph
+    P, n, hidden = 2, 2048, [16, 16]
+    A = _community_graph(n, P, 14, 0.95, seed=5)
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((n, 12)).astype(np.float32)
+    Y = rng.integers(0, 5, size=n)
+    d = pkg.datasets.prepare_dataset(str(tmp_path / "comm"), A, X, Y, P=P, partitioner="blocks")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_partitioned_worker, args=(r, P, port, d, hidden, q)) for r in range(P)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=300) for _ in range(P)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    (ip, ix, dv, nn, _), Xf, Yf, _ = pkg.datasets.read_dataset(d)
+    O = oracle.DistGcn(oracle.Csr(ip, ix, dv, nn), [Xf.shape[1]] + hidden + [1 + int(Yf.max())], P)
+    ol, oa = O.train_forward(Xf, Yf)
+    O.backward()
+    halo_rows = 0
+    for rank, out, n_ in res:
+        for mode in ("halo", "allgather"):
+            loss, acc, grads = out[mode]
+            assert abs(loss - ol) <= 1e-4 * abs(ol), (rank, mode, loss, ol)
+            for g, l in zip(grads, O.ranks[0]):
+                assert np.abs(g - l.lin.G_W).max() <= 1e-4 * np.abs(l.lin.G_W).max(), (rank, mode)
+        for gh, ga in zip(out["halo"][2], out["allgather"][2]):
+            assert np.abs(gh - ga).max() <= 1e-4 * np.abs(ga).max()
+        halo_rows += out["halo_rows"]
+    # both matrices (forward + backward) over all ranks vs the all-gather's (P - 1) n rows per matrix
+    assert halo_rows < 0.5 * 2 * (P - 1) * nn, (halo_rows, 2 * (P - 1) * nn)
