@@ -86,14 +86,13 @@ def main():
 
     # ---- workload ------------------------------------------------------------------
     t_gen = time.time()
-    (indptr, indices, data), X, Y = pkg.datasets.synth_reddit_like(args.scale, seed=1)
-    n, nnz = int(indptr.shape[0] - 1), int(indptr[-1])
-    num_labels = 1 + int(Y.max())
-    sizes = [X.shape[1]] + list(args.hidden) + [num_labels]
-    if P > 1:
-        sizes[-1] = (sizes[-1] + P - 1) // P * P            # reference src/main.cpp:135
     fused = not args.unfused
-    A = pkg.csr_matrix(indptr, indices, data, n)
+    if P == 1:
+        (indptr, indices, data), X, Y = pkg.datasets.synth_reddit_like(args.scale, seed=1)
+        n, nnz = int(indptr.shape[0] - 1), int(indptr[-1])
+        num_labels = 1 + int(Y.max())
+        sizes = [X.shape[1]] + list(args.hidden) + [num_labels]
+        A = pkg.csr_matrix(indptr, indices, data, n)
 
     if P == 1:
         ctx = pkg.context(local_rank)
@@ -105,34 +104,49 @@ def main():
             return G.train_step(ctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
         spmm_shape = (G.A_T.n(), G.A_T.m(), G.A_T.nnz())
     else:
+        # The synthetic graph is written ONCE in the reference's on-disk format (rank 0; the real Reddit would
+        # simply be there) and every rank reads only its own rows of it (dist.load_rank_local): no rank ever holds
+        # the whole A, A^T or the other ranks' blocks -- the reference's one process loads everything once
+        # (src/main.cpp:82-85); P processes doing the same would hold P copies on one host.
+        import shutil
+        import tempfile
         D = pkg.dist
         dctx = D.dist_context(overlap=not args.no_overlap, device_index=local_rank)
         ctx = dctx.ctx
-        A.normalize(True)                                    # src/main.cpp:143-144
-        A_T = A.transpose()
-        p = D.partition_bounds(n, P)
-        Ad = D.dist_row_csr_matrix(dctx, A, p, p)
-        A_Td = D.dist_row_csr_matrix(dctx, A_T, p, p)
+        tmp = os.path.join(tempfile.gettempdir(), f"mggcn_bench_{os.environ.get('MASTER_PORT', '0')}_{args.scale}")
+        if rank == 0:
+            (indptr, indices, data), X, Y = pkg.datasets.synth_reddit_like(args.scale, seed=1)
+            pkg.datasets.write_dataset(tmp, indptr, indices, data, X, Y)
+            del indptr, indices, data, X, Y
+        dist.barrier()
+        Ad, A_Td, Xd, Yd, info = D.load_rank_local(dctx, tmp)
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
+        n = info["n"]
+        nnz = int(dctx.host_all_reduce(np.array([info["nnz_local"]], dtype=np.int64))[0])
+        sizes = [info["features"]] + list(args.hidden) + [(info["num_labels"] + P - 1) // P * P]   # src/main.cpp:135
         G = D.dist_gcn(dctx, Ad, A_Td, sizes, fused=fused, mode=args.mode)
-        Xd = D.dist_row_dn_matrix(dctx, X)
-        Yd = D.dist_row_dn_matrix(dctx, Y)
 
         def epoch():
             return G.train_step(dctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
         spmm_shape = (A_Td.diag.n(), n, A_Td.diag.nnz() + A_Td.remote.nnz())
     t_gen = time.time() - t_gen
 
-    # the d = 128 SpMM timers of one epoch (reference timer names, src/gcn.hpp:32-35, :43-46)
+    # the SpMM timers of one epoch by width (reference timer names, src/gcn.hpp:32-35, :43-46): the d = 128
+    # calls are the dominant kernel (`roofline`), the logits-width calls the second (`roofline_narrow`)
     d_main = args.hidden[0]
     nl = len(sizes) - 1
-    spmm_timers = []
+    timers_by_width = {}
     for li in range(nl):
-        din, dout = sizes[li], sizes[li + 1]
-        w = min(din, dout)                       # width the SpMM runs at (gcn.hpp:439-446)
-        if w == d_main:
-            spmm_timers.append(f"{li}_0_matmul-spmm")
-            if li != 0:
-                spmm_timers.append(f"{li}_1_matmul-spmm")
+        w = min(sizes[li], sizes[li + 1])        # width the SpMM runs at (gcn.hpp:439-446)
+        names = timers_by_width.setdefault(w, [])
+        names.append(f"{li}_0_matmul-spmm")
+        if li != 0:
+            names.append(f"{li}_1_matmul-spmm")
+    spmm_timers = timers_by_width.get(d_main, [])
+    d_narrow = min(sizes[-2], sizes[-1])
+    narrow_timers = timers_by_width.get(d_narrow, []) if d_narrow != d_main else []
 
     def barrier():
         if P > 1:
@@ -142,12 +156,13 @@ def main():
     losses = []
     for _ in range(args.warmup):
         losses.append(epoch()[0])
-    spmm_ms = []
+    spmm_ms, narrow_ms = [], []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses.append(epoch()[0])
         spmm_ms.append([ctx.measure(t) for t in spmm_timers])     # hipEventElapsedTime, microseconds of host time
+        narrow_ms.append([ctx.measure(t) for t in narrow_timers])
     barrier()
     t1 = time.perf_counter()
     ms = (t1 - t0) * 1000.0 / max(args.steps, 1)
@@ -156,19 +171,47 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
 
-    spmm_ms = np.asarray(spmm_ms, dtype=np.float64)
-    spmm_avg = float(spmm_ms.mean()) if spmm_ms.size else float("nan")
-    nr, nc, nz = spmm_shape
-    b_alg = spmm_bytes_alg(nr, nc, nz, d_main)
-    b_gather = spmm_bytes_gather(nr, nz, d_main)
-    achieved = b_alg / (spmm_avg * 1e-3) / 1e9 if spmm_avg > 0 else float("nan")
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")     # written from a --pmc pass, if any
-    if P == 1 and os.path.exists(tf):
-        try:
-            traffic = json.load(open(tf)).get("bytes_per_launch")
-        except Exception:
-            traffic = None
+    def spmm_roofline(ms_lists, d, launches_per_call, traffic_key):
+        """achieved = ALGORITHMIC bytes of one SpMM call / its HIP-event time on the compute stream"""
+        a = np.asarray(ms_lists, dtype=np.float64)
+        if not a.size:
+            return None
+        avg, med, mn = float(a.mean()), float(np.median(a)), float(a.min())
+        nr, nc, nz = spmm_shape
+        b_alg = spmm_bytes_alg(nr, nc, nz, d)
+        ach = b_alg / (avg * 1e-3) / 1e9
+        traffic, src = None, None
+        tf = os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")     # written from separate --pmc passes
+        if P == 1 and os.path.exists(tf):
+            try:
+                j = json.load(open(tf))
+                traffic = j.get(traffic_key, j.get("bytes_per_launch") if traffic_key == "bytes_per_call" else None)
+                src = j.get("source")
+            except Exception:
+                traffic = None
+        return {"bound": "hbm", "kernel": f"spmm_csr_f32 d={d}", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                "frac_of_achievable_6300": round(ach / HBM_ACHIEVABLE_GBPS, 5),
+                # HBM-side bytes per CALL from rocprofv3 --pmc passes of an earlier run of the same kernels (this run
+                # measures time only): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed over the call's launches
+                "traffic": traffic, "traffic_source": src,
+                "ms_per_call": round(avg, 4), "ms_per_call_median": round(med, 4), "ms_per_call_min": round(mn, 4),
+                "kernel_launches_per_call": launches_per_call, "calls_timed": int(a.size), "bytes_alg": b_alg,
+                "gather_GBps": round(spmm_bytes_gather(nr, nz, d) / (avg * 1e-3) / 1e9, 1)}
+
+    def launches(d):
+        """average kernel launches of one SpMM call at width d over the calls of an epoch (forward and backward
+        matrices are cut differently); single GPU only"""
+        if P != 1:
+            return None
+        per = []
+        for layer in G.layers():
+            if min(layer.lin.W.n(), layer.lin.W.m()) != d:
+                continue
+            for buf in (layer.A.ext_buffer, layer.A.ext_buffer2):
+                if buf is not None:
+                    per.append(buf.num_launches(d))
+        return round(float(np.mean(per)), 2) if per else None
 
     out = {
         "metric": "epoch_ms (Reddit-shaped 3x128 GCN, full-graph, fp32)",
@@ -178,18 +221,17 @@ def main():
         "config": {"workload": "reddit_like_3x128_gcn" if args.scale == 1.0 else f"reddit_like_scale_{args.scale}",
                    "n": n, "nnz": nnz, "sizes": sizes, "spmm_per_epoch": 2 * nl - 1,
                    "parallelism": f"rows{P}" + ("" if P == 1 else f"-{args.mode}"), "fused": fused},
-        "roofline": {"bound": "hbm", "kernel": f"spmm_csr_f32 d={d_main}", "achieved": round(achieved, 2),
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                     "frac_of_achievable_6300": round(achieved / HBM_ACHIEVABLE_GBPS, 5),
-                     "traffic": traffic, "ms_per_launch": round(spmm_avg, 4), "bytes_alg": b_alg,
-                     "gather_GBps": round(b_gather / (spmm_avg * 1e-3) / 1e9, 1) if spmm_avg > 0 else None,
-                     "launches_timed": int(spmm_ms.size)},
+        "roofline": spmm_roofline(spmm_ms, d_main, launches(d_main), "bytes_per_call"),
+        "roofline_narrow": spmm_roofline(narrow_ms, d_narrow, launches(d_narrow), "bytes_per_call_narrow") if narrow_timers else None,
         "loss_first_last": [round(float(losses[0]), 5), round(float(losses[-1]), 5)] if losses else None,
         "setup_s": round(t_gen, 1),
     }
 
     if rank == 0 and P == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d_main)
+        if args.warmup + args.steps > 0 and "loss" in out["cpu_baseline"]:
+            out["cpu_baseline"]["loss_matches_gpu_first"] = bool(
+                abs(out["cpu_baseline"]["loss"] - losses[0]) <= 1e-4 * abs(out["cpu_baseline"]["loss"]))
 
     if P > 1:
         dist.barrier()
@@ -216,17 +258,30 @@ def cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d):
     A_T = orc.transpose(A)
     B = np.random.default_rng(0).standard_normal((n, d), dtype=np.float32)
     orc.spmm(A_T, B[: A_T.m])                    # warm-up (page faults, thread pool)
-    t = time.perf_counter(); orc.spmm(A_T, B); t_spmm = time.perf_counter() - t
+    ts = []
+    for _ in range(3):                           # median + min
+        t = time.perf_counter(); orc.spmm(A_T, B); ts.append(time.perf_counter() - t)
+    t_spmm = float(np.median(ts))
     nl = len(sizes) - 1
     projected = t_spmm * (2 * nl - 1) * 1.6      # SpMMs dominate; GEMM/elementwise ~ +60 % on CPU
-    res = {"unit": "ms", "cores": cores, "kind": "port",
-           "spmm_ms": round(t_spmm * 1e3, 1),
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    res = {"unit": "ms", "cores": cores, "cpu_model": model, "kind": "port",
+           "spmm_ms": round(t_spmm * 1e3, 1), "spmm_ms_min": round(min(ts) * 1e3, 1),
            "spmm_GBps_alg": round(spmm_bytes_alg(n, n, A.nnz, d) / t_spmm / 1e9, 2)}
     if projected <= 45.0:
         O = orc.Gcn(orc.Csr(indptr, indices, data, n), sizes)
         t = time.perf_counter()
-        O.train_forward(X, Y); O.backward(); O.adam_update()
+        loss0, _ = O.train_forward(X, Y); O.backward(); O.adam_update()
         res["value"] = round((time.perf_counter() - t) * 1e3, 1)
+        res["loss"] = round(float(loss0), 5)     # epoch-0 loss of the oracle: compare with loss_first (same weights, same inputs)
         res["sample"] = "1 full epoch of the same workload (oracle.Gcn, fp32, OpenMP)"
     else:
         frac = max(0.02, 20.0 / projected)

@@ -100,7 +100,12 @@ void mggcn_memset_zero(void *dst, size_t bytes, mggcn_stream_t stream);
  *    in the same order and the active panel stays L2-resident (a private device copy
  *    of the matrix, 8 B per non-zero).  Pass NULL for both to skip it.
  * The arrays later passed to mggcn_spmm_csr_f32 with a plan must hold the matrix the
- * plan was built for (the sweep form reads its own copy). */
+ * plan was built for (the sweep form reads its own copy).
+ * Re-entrancy: every entry point of this header is enqueue-only and may be called from any stream, but a
+ * PLAN owns mutable device scratch (partial-sum slots of sliced rows, the re-pitched copy of B of the narrow
+ * form): one plan may be in flight on ONE stream at a time.  Calls on the same stream are ordered and safe;
+ * to multiply by the same matrix on two streams concurrently, build two plans.  The same holds for
+ * mggcn_abssum_f32, whose two-level reduction uses a per-device scratch. */
 typedef struct mggcn_spmm_plan mggcn_spmm_plan;
 
 mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,
@@ -120,6 +125,7 @@ void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan);
 uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan);
 uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan);
 uint32_t mggcn_spmm_plan_num_sweep_tasks(const mggcn_spmm_plan *plan); /* 0: no sweep form */
+uint32_t mggcn_spmm_plan_num_launches(const mggcn_spmm_plan *plan, uint32_t d); /* kernel launches per SpMM call at width d */
 size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan);
 
 /* flags */

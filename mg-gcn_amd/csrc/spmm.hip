@@ -440,6 +440,15 @@ MGGCN_API size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan) {
     for (auto *sp : plan->sweeps) b += sweep_plan_bytes(sp);
     return b;
 }
+MGGCN_API uint32_t mggcn_spmm_plan_num_launches(const mggcn_spmm_plan *plan, uint32_t d) {
+    // kernel launches one mggcn_spmm_csr_f32 call makes with this plan at width d (aligned operands assumed)
+    if (!plan) return 1;
+    if (plan->sweeps.empty()) return 1 + (plan->n_split_rows ? 1 : 0);
+    uint32_t n = (plan->d_bpad && (d + 15) / 16 * 16 <= plan->bpad_dp && d % 16 != 0) ? 1u : 0u;   // re-pitch pass
+    for (auto *sp : plan->sweeps) n += sweep_plan_launches(sp, d);
+    return n;
+}
+
 MGGCN_API uint32_t mggcn_spmm_plan_num_sweep_tasks(const mggcn_spmm_plan *plan) {
     uint32_t t = 0;
     for (auto *sp : plan->sweeps) t += sweep_plan_tasks(sp);

@@ -888,6 +888,15 @@ size_t sweep_plan_bytes(const SweepPlan *p) { return p ? p->bytes : 0; }
 uint32_t sweep_plan_tasks(const SweepPlan *p) { return p ? p->n_tasks : 0; }
 uint32_t sweep_plan_split_rows(const SweepPlan *p) { return p ? p->n_split_rows : 0; }
 
+uint32_t sweep_plan_launches(const SweepPlan *p, uint32_t d) {
+    if (!p) return 0;
+    const bool quad = p->lpe && d <= 4 * p->lpe;
+    const bool vec4 = p->run_pad % 2 == 0 && d >= 96 && d % 4 == 0;
+    const bool vec2 = d > 64 && d % 2 == 0;
+    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
+    return (p->n_tasks + per_launch - 1) / per_launch + (p->n_split_rows ? 1u : 0u);
+}
+
 bool sweep_supports(const SweepPlan *p, uint32_t d, size_t ldb, size_t ldc, const void *B, const void *C) {
     if (!p) return false;
     if (p->n_slots && d > p->max_d) return false;

@@ -32,6 +32,7 @@ class spmm_buffer:
     def num_items(self) -> int: return self.lib.mggcn_spmm_plan_num_items(self.handle)
     def num_split_rows(self) -> int: return self.lib.mggcn_spmm_plan_num_split_rows(self.handle)
     def num_sweep_tasks(self) -> int: return self.lib.mggcn_spmm_plan_num_sweep_tasks(self.handle)
+    def num_launches(self, d: int) -> int: return self.lib.mggcn_spmm_plan_num_launches(self.handle, int(d))
     def nbytes(self) -> int: return self.lib.mggcn_spmm_plan_bytes(self.handle)
 
     def __del__(self):
