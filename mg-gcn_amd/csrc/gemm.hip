@@ -73,11 +73,12 @@ __device__ __forceinline__ float4 load4_guard(const float *__restrict__ p, long 
 // One operand's tile staging.  R = rows of the tile in the M (or N) direction.
 // KCONTIG: the stored matrix is [R-dim][K] (K contiguous) -> transpose into Xs[k][r].
 // else   : the stored matrix is [K][R-dim] (R contiguous) -> straight copy.
-template <int R, bool KCONTIG>
+template <int R, bool KCONTIG, int NT>
 struct Stager {
     static constexpr int PAD = KCONTIG ? 1 : 4;
     static constexpr int LD = R + PAD;
-    static constexpr int SEGS = R * BK / 4 / 256;   // float4 segments per thread
+    static constexpr int SEGS = R * BK / 4 / NT;    // float4 segments per thread
+    static_assert(SEGS >= 1 && R * BK / 4 % NT == 0, "tile does not divide over the threads");
     float4 reg[SEGS];
 
     __device__ __forceinline__ void load(const float *__restrict__ X, size_t ld, long long r0,
@@ -85,7 +86,7 @@ struct Stager {
                                          int tid) {
 #pragma unroll
         for (int s = 0; s < SEGS; s++) {
-            const int f = tid + 256 * s;
+            const int f = tid + NT * s;
             if (KCONTIG) {
                 const int r = f / (BK / 4), kq = f % (BK / 4);
                 const long long row = r0 + r;
@@ -103,7 +104,7 @@ struct Stager {
     __device__ __forceinline__ void store(float *__restrict__ Xs, int tid) const {
 #pragma unroll
         for (int s = 0; s < SEGS; s++) {
-            const int f = tid + 256 * s;
+            const int f = tid + NT * s;
             if (KCONTIG) {
                 const int r = f / (BK / 4), kq = f % (BK / 4);
                 Xs[(kq * 4 + 0) * LD + r] = reg[s].x;
@@ -118,19 +119,29 @@ struct Stager {
     }
 };
 
-template <bool A_KCONTIG, bool B_KCONTIG, int BN>
-__global__ __launch_bounds__(256) void gemm_mfma_kernel(
+// NT = 256: 4 waves, each 64x64 (BN = 128) or 32x64 (BN = 64) of the tile -- 64 / 32 accumulator registers, ~170 VGPRs,
+//           two workgroups = 2 waves per SIMD.
+// NT = 512: 8 waves, each 32x64 (BN = 128) or 32x32 (BN = 64) -- half the accumulators per wave, ~90 VGPRs, two
+//           workgroups = 4 waves per SIMD: the matrix pipe of a SIMD keeps running while some of its waves sit at
+//           the workgroup barrier or wait for their LDS stores (r01 counters on [n x 608].[608 x 128]: MFMA pipe 55 %
+//           busy, waves parked on s_waitcnt / s_barrier 39 % of their cycles with two waves per SIMD).
+// The K loop is double-buffered in LDS: tile k+1 is written to the other buffer after the MFMAs of tile k, ONE
+// barrier per K-step (the single-buffer loop needed two and serialised store -> compute).
+template <bool A_KCONTIG, bool B_KCONTIG, int BN, int NT>
+__global__ __launch_bounds__(NT) void gemm_mfma_kernel(
     uint32_t M, uint32_t N, uint32_t K, float alpha, const float *__restrict__ A, size_t lda,
     const float *__restrict__ B, size_t ldb, float beta, float *__restrict__ C, size_t ldc,
     float *__restrict__ slab, uint32_t k_chunk, bool a_vec, bool b_vec, const Epilogue epi) {
-    constexpr int WN = BN == 128 ? 2 : 1;           // waves along N
-    constexpr int WM = 4 / WN;                      // waves along M
-    constexpr int MI = BM / WM / 32;                // MFMA blocks per wave along M (2 or 1)
-    constexpr int NI = BN / WN / 32;                // along N (2)
-    using StA = Stager<BM, A_KCONTIG>;
-    using StB = Stager<BN, B_KCONTIG>;
-    __shared__ __attribute__((aligned(16))) float As[BK * StA::LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * StB::LD];
+    constexpr int NW = NT / 64;
+    constexpr int WN = (BN == 128 || NW == 8) ? 2 : 1;   // waves along N
+    constexpr int WM = NW / WN;                     // waves along M
+    constexpr int MI = BM / WM / 32;                // MFMA blocks per wave along M
+    constexpr int NI = BN / WN / 32;                // along N
+    static_assert(MI >= 1 && NI >= 1, "wave tile smaller than one MFMA block");
+    using StA = Stager<BM, A_KCONTIG, NT>;
+    using StB = Stager<BN, B_KCONTIG, NT>;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * StA::LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * StB::LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -151,32 +162,39 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(
     if (k_begin < k_end) {
         sa.load(A, lda, m0, M, k_begin, k_end, a_vec, tid);
         sb.load(B, ldb, n0, N, k_begin, k_end, b_vec, tid);
+        sa.store(As[0], tid);
+        sb.store(Bs[0], tid);
     }
+    __syncthreads();
     const int l31 = lane & 31, lhi = lane >> 5;
-    for (long long k0 = k_begin; k0 < k_end; k0 += BK) {
-        __syncthreads();                 // previous step's LDS reads are done
-        sa.store(As, tid);
-        sb.store(Bs, tid);
-        __syncthreads();
-        if (k0 + BK < k_end) {           // prefetch the next K-step under the MFMAs
+    int cur = 0;
+    for (long long k0 = k_begin; k0 < k_end; k0 += BK, cur ^= 1) {
+        const bool more = k0 + BK < k_end;
+        if (more) {                      // global loads of the next K-step fly under the MFMAs
             sa.load(A, lda, m0, M, k0 + BK, k_end, a_vec, tid);
             sb.load(B, ldb, n0, N, k0 + BK, k_end, b_vec, tid);
         }
+        const float *as = As[cur], *bs = Bs[cur];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; kk++) {
             float a[MI], b[NI];
 #pragma unroll
             for (int i = 0; i < MI; i++)
-                a[i] = As[(kk * 2 + lhi) * StA::LD + wm * (BM / WM) + i * 32 + l31];
+                a[i] = as[(kk * 2 + lhi) * StA::LD + wm * (BM / WM) + i * 32 + l31];
 #pragma unroll
             for (int j = 0; j < NI; j++)
-                b[j] = Bs[(kk * 2 + lhi) * StB::LD + wn * (BN / WN) + j * 32 + l31];
+                b[j] = bs[(kk * 2 + lhi) * StB::LD + wn * (BN / WN) + j * 32 + l31];
 #pragma unroll
             for (int i = 0; i < MI; i++)
 #pragma unroll
                 for (int j = 0; j < NI; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (more) {                      // the other buffer: nobody reads it until the barrier below
+            sa.store(As[cur ^ 1], tid);
+            sb.store(Bs[cur ^ 1], tid);
+        }
+        __syncthreads();
     }
 
     // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -293,6 +311,16 @@ struct Split {
 };
 
 constexpr uint32_t kThinRows = 4;
+
+// threads per workgroup of the MFMA kernel (see gemm_mfma_kernel); MGGCN_GEMM_THREADS = 256 | 512 for experiments
+inline int gemm_threads() {
+    static const int nt = [] {
+        const char *e = std::getenv("MGGCN_GEMM_THREADS");
+        const int v = e ? std::atoi(e) : 512;
+        return v == 256 ? 256 : 512;
+    }();
+    return nt;
+}
 
 inline bool use_thin(int trans_a, int trans_b, uint32_t M, uint32_t K) {
     return !trans_a && !trans_b && M <= kThinRows && K >= 4096;
@@ -418,22 +446,27 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
     const bool b_vec = aligned16(B) && ldb % 4 == 0;
     const bool a_kc = !trans_a, b_kc = trans_b != 0;
     const int bn = N > 64 ? 128 : 64;
-    const dim3 grid((M + BM - 1) / BM, (N + bn - 1) / bn, sp.splits), block(256);
+    const dim3 grid((M + BM - 1) / BM, (N + bn - 1) / bn, sp.splits);
 
-#define MGGCN_GEMM_LAUNCH(AK, BKC, BNV)                                                               \
-    hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKC, BNV>), grid, block, 0, st, M, N, K, alpha, A, lda, B, ldb, \
+    const int nt = gemm_threads();
+    const dim3 blk(nt);
+#define MGGCN_GEMM_LAUNCH(AK, BKC, BNV, NTV)                                                               \
+    hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKC, BNV, NTV>), grid, blk, 0, st, M, N, K, alpha, A, lda, B, ldb, \
                        beta, C, ldc, slab, sp.k_chunk, a_vec, b_vec, epi)
+#define MGGCN_GEMM_LAUNCH_NT(AK, BKC, BNV) \
+    do { if (nt == 512) MGGCN_GEMM_LAUNCH(AK, BKC, BNV, 512); else MGGCN_GEMM_LAUNCH(AK, BKC, BNV, 256); } while (0)
     if (bn == 128) {
-        if (a_kc && b_kc) MGGCN_GEMM_LAUNCH(true, true, 128);
-        else if (a_kc) MGGCN_GEMM_LAUNCH(true, false, 128);
-        else if (b_kc) MGGCN_GEMM_LAUNCH(false, true, 128);
-        else MGGCN_GEMM_LAUNCH(false, false, 128);
+        if (a_kc && b_kc) MGGCN_GEMM_LAUNCH_NT(true, true, 128);
+        else if (a_kc) MGGCN_GEMM_LAUNCH_NT(true, false, 128);
+        else if (b_kc) MGGCN_GEMM_LAUNCH_NT(false, true, 128);
+        else MGGCN_GEMM_LAUNCH_NT(false, false, 128);
     } else {
-        if (a_kc && b_kc) MGGCN_GEMM_LAUNCH(true, true, 64);
-        else if (a_kc) MGGCN_GEMM_LAUNCH(true, false, 64);
-        else if (b_kc) MGGCN_GEMM_LAUNCH(false, true, 64);
-        else MGGCN_GEMM_LAUNCH(false, false, 64);
+        if (a_kc && b_kc) MGGCN_GEMM_LAUNCH_NT(true, true, 64);
+        else if (a_kc) MGGCN_GEMM_LAUNCH_NT(true, false, 64);
+        else if (b_kc) MGGCN_GEMM_LAUNCH_NT(false, true, 64);
+        else MGGCN_GEMM_LAUNCH_NT(false, false, 64);
     }
+#undef MGGCN_GEMM_LAUNCH_NT
 #undef MGGCN_GEMM_LAUNCH
     MGGCN_CHECK_LAUNCH();
     if (sp.splits > 1) {

@@ -126,7 +126,11 @@ static void compare(std::size_t P, const epoch_result &d, const epoch_result &s,
     const double tol = 1e-4;
     CHECK(std::fabs(d.loss[0] - s.loss[0]) <= tol * std::fabs(s.loss[0]));
     CHECK(std::fabs(d.acc[0] - s.acc[0]) <= 3.0 / n);
-    CHECK(std::fabs(d.loss[1] - s.loss[1]) <= 2e-3 * std::fabs(s.loss[1]));     // after one Adam step: ~ lr * sign(g) drift
+    // second epoch: one Adam step apart.  Adam's first step is lr * g / (|g| + eps): where |g| is rounding noise its sign
+    // -- hence a whole 0.01 step of that weight -- differs between two correct summation orders, so P > 1 (regrouped
+    // sums) may move away from the single-GPU trajectory by a fraction of a percent; P = 1 must not.
+    CHECK(std::fabs(d.loss[1] - s.loss[1]) <= (P == 1 ? 1e-6 : 2e-2) * std::fabs(s.loss[1]));
+    CHECK(d.loss[1] < d.loss[0]);
     for (std::size_t l = 0; l < s.G_W.size(); l++) {
         if (P == 1) {
             CHECK(d.G_W[l] == s.G_W[l]);
@@ -166,9 +170,9 @@ int main(int argc, char **argv) {
                 const auto dist = run_dist(P, A, sizes, X, Y, fused, mode, overlap, &transport);
                 compare(P, dist, single, (double)n);
                 const char *mn = mode == dist_mode::allgather ? "allgather" : mode == dist_mode::halo ? "halo" : "rounds";
-                std::printf("%s: dist_gcn P=%zu %s overlap=%d fused=%d transport=%s  loss %.7f (single GPU %.7f)\n",
+                std::printf("%s: dist_gcn P=%zu %s overlap=%d fused=%d transport=%s  loss %.7f -> %.7f (single GPU %.7f -> %.7f)\n",
                             g_failures == before ? "TEST PASSED" : "TEST FAILED", P, mn, (int)overlap, (int)fused, transport.c_str(),
-                            dist.loss[0], single.loss[0]);
+                            dist.loss[0], dist.loss[1], single.loss[0], single.loss[1]);
             }
     }
     // halo volume matrix of the partition (the figure test/data/prep.py:237-244 prints)
