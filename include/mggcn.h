@@ -104,8 +104,8 @@ void mggcn_memset_zero(void *dst, size_t bytes, mggcn_stream_t stream);
  * Re-entrancy: every entry point of this header is enqueue-only and may be called from any stream, but a
  * PLAN owns mutable device scratch (partial-sum slots of sliced rows, the re-pitched copy of B of the narrow
  * form): one plan may be in flight on ONE stream at a time.  Calls on the same stream are ordered and safe;
- * to multiply by the same matrix on two streams concurrently, build two plans.  The same holds for
- * mggcn_abssum_f32, whose two-level reduction uses a per-device scratch. */
+ * to multiply by the same matrix on two streams concurrently, build two plans.  (mggcn_abssum_f32 keeps its
+ * reduction scratch per stream: concurrent sums on different streams are safe.) */
 typedef struct mggcn_spmm_plan mggcn_spmm_plan;
 
 mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,

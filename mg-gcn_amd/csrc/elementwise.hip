@@ -10,6 +10,10 @@
 // passes over [n x m] fp32; none is reshaped into a GEMM.
 #include <algorithm>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -238,15 +242,19 @@ __global__ __launch_bounds__(256) void abssum_final_kernel(const float *__restri
     if (threadIdx.x == 0) *result = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-// per-device scratch for the abssum partials, allocated on first use (never on a
-// captured launch path: the host layers call abssum once during warm-up)
-float *abssum_scratch() {
-    static float *scratch[64] = {nullptr};
+// scratch for the abssum partials: one per (device, stream), allocated on first use (never on a captured
+// launch path: the host layers call abssum once during warm-up).  Per STREAM, not per device: several
+// contexts may drive one GPU at once (a dist_context whose ranks share a device, two models on two
+// streams) and two sums in flight on different streams must not share their partials.
+float *abssum_scratch(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, float *> scratch;
     int dev = 0;
     MGGCN_CHECK_HIP(hipGetDevice(&dev));
-    MGGCN_REQUIRE(dev >= 0 && dev < 64, "device ordinal out of range");
-    if (!scratch[dev]) MGGCN_CHECK_HIP(hipMalloc(&scratch[dev], kAsumBlocks * sizeof(float)));
-    return scratch[dev];
+    std::lock_guard<std::mutex> lock(mu);
+    float *&p = scratch[{dev, st}];
+    if (!p) MGGCN_CHECK_HIP(hipMalloc(&p, kAsumBlocks * sizeof(float)));
+    return p;
 }
 
 // ---- fused softmax + cross-entropy + argmax + gradient ---------------------
@@ -503,7 +511,7 @@ MGGCN_API void mggcn_scale_mat_f32(mggcn_stream_t stream, float *mat, float scal
 
 MGGCN_API void mggcn_abssum_f32(mggcn_stream_t stream, const float *A, size_t size, float *result_device) {
     MGGCN_REQUIRE(result_device != nullptr, "null result pointer");
-    float *scratch = abssum_scratch();
+    float *scratch = abssum_scratch(as_stream(stream));
     const unsigned blocks = std::min<unsigned>(kAsumBlocks, stream_grid(size ? size : 1));
     hipLaunchKernelGGL(abssum_partial_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), A, size, scratch);
     MGGCN_CHECK_LAUNCH();
