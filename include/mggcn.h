@@ -164,6 +164,15 @@ void mggcn_gemm_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M,
 void mggcn_gemm_bias_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
                          uint32_t K, float alpha, const float *A, size_t lda, const float *B, size_t ldb,
                          const float *bias, float *C, size_t ldc, void *workspace, size_t workspace_bytes);
+/* C = alpha * A^T * B  AND  colsum = alpha * 1^T B  in one pass (A stored [K x M], B stored [K x N]).
+ * The reference's linear::backward runs G_b = 1^T G as an sgemm with a ones vector and then G_W = X^T G
+ * (src/gcn.hpp:125-134): two passes over G.  Here the workgroups of the first M-tile add up the B tiles they stage for
+ * the MFMAs anyway -- no second read of G, no extra launch.  Split-K slabs carry the sums as one extra row; combined in
+ * the same fixed order (reproducible).  Workspace: mggcn_gemm_tn_colsum_workspace_bytes. */
+size_t mggcn_gemm_tn_colsum_workspace_bytes(uint32_t M, uint32_t N, uint32_t K);
+void mggcn_gemm_tn_colsum_f32(mggcn_stream_t stream, uint32_t M, uint32_t N, uint32_t K, float alpha, const float *A,
+                              size_t lda, const float *B, size_t ldb, float *C, size_t ldc, float *colsum,
+                              void *workspace, size_t workspace_bytes);
 /* C = (alpha * op(A) * op(B)) .* (Z > 0 ? 1 : slope)   (Z: M x N, ldz >= N; C is never read).
  * Folds the NEXT leaky_relu_backward launch into the GEMM that produces its gradient operand: the reference
  * runs G_out = G . W^T in layer i+1 (src/gcn.hpp:135-137) and then, in layer i, leaky_relu_backward(Z_i, G_out)

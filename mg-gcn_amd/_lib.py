@@ -61,6 +61,9 @@ PROTOTYPES = {
                               c_size_t, c_float, vp, c_size_t, vp, c_size_t]),
     "mggcn_gemm_bias_f32": (None, [vp, c_int, c_int, c_uint32, c_uint32, c_uint32, c_float, vp, c_size_t, vp,
                                    c_size_t, vp, vp, c_size_t, vp, c_size_t]),
+    "mggcn_gemm_tn_colsum_workspace_bytes": (c_size_t, [c_uint32, c_uint32, c_uint32]),
+    "mggcn_gemm_tn_colsum_f32": (None, [vp, c_uint32, c_uint32, c_uint32, c_float, vp, c_size_t, vp, c_size_t, vp,
+                                        c_size_t, vp, vp, c_size_t]),
     "mggcn_gemm_lrelu_bwd_f32": (None, [vp, c_int, c_int, c_uint32, c_uint32, c_uint32, c_float, vp, c_size_t, vp,
                                         c_size_t, vp, c_size_t, c_float, vp, c_size_t, vp, c_size_t]),
     "mggcn_leaky_relu_forward_f32": (None, [vp, vp, vp, c_size_t, c_float]),

@@ -261,7 +261,10 @@ float *abssum_scratch(hipStream_t st) {
 // One wave64 per row; the row's m <= 64*K logits live in K registers per lane.
 constexpr int kXentMaxPerLane = 16;  // m <= 1024
 
-template <int K>
+// R rows are in flight per wave (their loads issued together): with one row at a time every row is a dependent
+// HBM round trip -- load, six shuffle steps, store -- and the pass was latency-bound at 0.7 TB/s (r01: 110 us for
+// the 76 MB of the [233 k x 41] logits); four rows in flight hide it.
+template <int K, int R>
 __global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restrict__ H,
                                                                  const int32_t *__restrict__ Y,
                                                                  size_t n_rows, size_t m, float grad_scale,
@@ -270,48 +273,63 @@ __global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restri
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t wstride = ((size_t)gridDim.x * blockDim.x) >> 6;
     float loss_acc = 0.f, corr_acc = 0.f;
-    for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < n_rows; r += wstride) {
-        float x[K];
-        float mx = -INFINITY;
-        uint32_t idx = 0xFFFFFFFFu;
+    for (size_t r0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r0 < n_rows; r0 += wstride * R) {
+        float x[R][K];
+        int32_t y[R];
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const size_t c = (size_t)lane + 64u * k;
-            x[k] = c < m ? H[r * m + c] : -INFINITY;
-            if (x[k] > mx) { mx = x[k]; idx = (uint32_t)c; }
-        }
+        for (int q = 0; q < R; q++) {                     // all loads first
+            const size_t r = r0 + (size_t)q * wstride;
+            const bool live = r < n_rows;                 // wave-uniform
+            y[q] = live ? Y[r] : 0;
 #pragma unroll
-        for (int off = 32; off; off >>= 1) {
-            const float ov = __shfl_xor(mx, off);
-            const uint32_t oi = __shfl_xor(idx, off);
-            argmax_combine(mx, idx, ov, oi);
-        }
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const size_t c = (size_t)lane + 64u * k;
-            x[k] = c < m ? expf(x[k] - mx) : 0.f;
-            sum += x[k];
-        }
-        sum = wave_sum(sum);
-        const int32_t y = Y[r];
-        float py = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const size_t c = (size_t)lane + 64u * k;
-            if (c < m) {
-                const float o = x[k] / sum;
-                const bool hit = (int32_t)c == y;
-                if (hit) py = o;
-                H[r * m + c] = (hit ? o - 1.f : o) * grad_scale;
+            for (int k = 0; k < K; k++) {
+                const size_t c = (size_t)lane + 64u * k;
+                x[q][k] = (live && c < m) ? H[r * m + c] : -INFINITY;
             }
         }
-        py = wave_sum(py);  // exactly one lane holds p_y
-        if (lane == 0) {
-            loss_acc += fabsf(logf(py));
-            // argmax of the softmax output == argmax of the logits (exp is monotone);
-            // a row whose maximum never beat -inf reports index 0 like the reference
-            corr_acc += ((idx == 0xFFFFFFFFu ? 0 : (int32_t)idx) == y) ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const size_t r = r0 + (size_t)q * wstride;
+            if (r >= n_rows) break;                       // wave-uniform
+            float mx = -INFINITY;
+            uint32_t idx = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const size_t c = (size_t)lane + 64u * k;
+                if (x[q][k] > mx) { mx = x[q][k]; idx = (uint32_t)c; }
+            }
+#pragma unroll
+            for (int off = 32; off; off >>= 1) {
+                const float ov = __shfl_xor(mx, off);
+                const uint32_t oi = __shfl_xor(idx, off);
+                argmax_combine(mx, idx, ov, oi);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const size_t c = (size_t)lane + 64u * k;
+                x[q][k] = c < m ? expf(x[q][k] - mx) : 0.f;
+                sum += x[q][k];
+            }
+            sum = wave_sum(sum);
+            float py = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const size_t c = (size_t)lane + 64u * k;
+                if (c < m) {
+                    const float o = x[q][k] / sum;
+                    const bool hit = (int32_t)c == y[q];
+                    if (hit) py = o;
+                    H[r * m + c] = (hit ? o - 1.f : o) * grad_scale;
+                }
+            }
+            py = wave_sum(py);  // exactly one lane holds p_y
+            if (lane == 0) {
+                loss_acc += fabsf(logf(py));
+                // argmax of the softmax output == argmax of the logits (exp is monotone);
+                // a row whose maximum never beat -inf reports index 0 like the reference
+                corr_acc += ((idx == 0xFFFFFFFFu ? 0 : (int32_t)idx) == y[q]) ? 1.f : 0.f;
+            }
         }
     }
     if (lane == 0) { s_loss[wid] = loss_acc; s_acc[wid] = corr_acc; }
@@ -526,14 +544,14 @@ MGGCN_API void mggcn_softmax_xent_fused_f32(mggcn_stream_t stream, float *H, con
     MGGCN_REQUIRE(m > 0 && m <= 64u * kXentMaxPerLane, "fused loss supports 1 <= m <= 1024 classes");
     const dim3 grid(stream_grid(n_rows * 64)), block(256);
     hipStream_t st = as_stream(stream);
-#define MGGCN_XENT(K)                                                                              \
-    hipLaunchKernelGGL(softmax_xent_fused_kernel<K>, grid, block, 0, st, H, Y, n_rows, m, grad_scale, \
+#define MGGCN_XENT(K, R)                                                                              \
+    hipLaunchKernelGGL((softmax_xent_fused_kernel<K, R>), grid, block, 0, st, H, Y, n_rows, m, grad_scale, \
                        sums_device)
-    if (m <= 64) MGGCN_XENT(1);
-    else if (m <= 128) MGGCN_XENT(2);
-    else if (m <= 256) MGGCN_XENT(4);
-    else if (m <= 512) MGGCN_XENT(8);
-    else MGGCN_XENT(16);
+    if (m <= 64) MGGCN_XENT(1, 4);
+    else if (m <= 128) MGGCN_XENT(2, 4);
+    else if (m <= 256) MGGCN_XENT(4, 2);
+    else if (m <= 512) MGGCN_XENT(8, 1);
+    else MGGCN_XENT(16, 1);
 #undef MGGCN_XENT
     MGGCN_CHECK_LAUNCH();
 }

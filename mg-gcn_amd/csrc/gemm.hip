@@ -43,6 +43,7 @@ struct Epilogue {
     const float *mask = nullptr;     // .* (Z > 0 ? 1 : slope) (mggcn_gemm_lrelu_bwd_f32)
     size_t ldz = 0;
     float slope = 0.f;
+    float *colsum = nullptr;         // also 1^T op(B) -> colsum[N]   (mggcn_gemm_tn_colsum_f32; B stored [K][N])
 };
 
 __device__ __forceinline__ float epilogue_value(const Epilogue &e, float av, float beta, const float *cp, size_t row, size_t col) {
@@ -159,9 +160,24 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(
 
     StA sa;
     StB sb;
+    // column sums of B (G_b = 1^T G riding on G_W = X^T G): the workgroups of the FIRST M-tile add up the B tiles
+    // they stage anyway -- thread tid always holds columns (tid % (BN/4))*4 .. +3 of its k rows
+    const bool do_colsum = !B_KCONTIG && epi.colsum != nullptr && blockIdx.x == 0;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add_colsum = [&]() {
+        if constexpr (!B_KCONTIG) {
+            if (do_colsum) {
+#pragma unroll
+                for (int q = 0; q < StB::SEGS; q++) {
+                    csum.x += sb.reg[q].x; csum.y += sb.reg[q].y; csum.z += sb.reg[q].z; csum.w += sb.reg[q].w;
+                }
+            }
+        }
+    };
     if (k_begin < k_end) {
         sa.load(A, lda, m0, M, k_begin, k_end, a_vec, tid);
         sb.load(B, ldb, n0, N, k_begin, k_end, b_vec, tid);
+        add_colsum();
         sa.store(As[0], tid);
         sb.store(Bs[0], tid);
     }
@@ -191,10 +207,33 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (more) {                      // the other buffer: nobody reads it until the barrier below
+            add_colsum();
             sa.store(As[cur ^ 1], tid);
             sb.store(Bs[cur ^ 1], tid);
         }
         __syncthreads();
+    }
+    if constexpr (!B_KCONTIG) {
+        if (do_colsum) {                 // block-uniform.  Fold the NT / (BN/4) threads of a column group in order.
+            float4 *red = reinterpret_cast<float4 *>(As[0]);          // all tiles are consumed: reuse the LDS
+            red[tid] = csum;
+            __syncthreads();
+            if (tid < BN / 4) {
+                float4 t = red[tid];
+                for (int g = 1; g < NT / (BN / 4); g++) {
+                    const float4 o = red[tid + g * (BN / 4)];
+                    t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+                }
+                const float tv[4] = {t.x, t.y, t.z, t.w};
+                // split-K: row M of this slice's slab (reduced with the rest); otherwise straight to the result
+                float *dst = gridDim.z > 1 ? slab + ((size_t)blockIdx.z * (M + 1) + M) * N : epi.colsum;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const long long col = n0 + tid * 4 + c;
+                    if (col < N) dst[col] = gridDim.z > 1 ? tv[c] : alpha * tv[c];
+                }
+            }
+        }
     }
 
     // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -210,7 +249,7 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(
                 if (row < M && col < N) {
                     const float v = acc[i][j][r];
                     if (to_slab) {
-                        slab[((size_t)blockIdx.z * M + row) * N + col] = v;
+                        slab[((size_t)blockIdx.z * (M + (epi.colsum ? 1 : 0)) + row) * N + col] = v;
                     } else {
                         float *cp = C + (size_t)row * ldc + col;
                         *cp = epilogue_value(epi, alpha * v, beta, cp, (size_t)row, (size_t)col);
@@ -229,7 +268,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float *__
                                                                  float *__restrict__ C, size_t ldc,
                                                                  const Epilogue epi) {
     __shared__ float part[8][33];
-    const uint32_t total = M * N;                    // < 2^32: checked by the launcher
+    // with a column-sum row the slabs hold M + 1 rows; row M goes to epi.colsum instead of C
+    const uint32_t total = (M + (epi.colsum ? 1u : 0u)) * N;   // < 2^32: checked by the launcher
     const uint32_t lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
     for (uint32_t base = blockIdx.x * 32; base < total; base += gridDim.x * 32) {
         const uint32_t i = base + lane;
@@ -244,8 +284,12 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float *__
             float t = part[0][lane];
 #pragma unroll
             for (int g = 1; g < 8; g++) t += part[g][lane];
-            float *cp = C + (size_t)(i / N) * ldc + (i % N);
-            *cp = epilogue_value(epi, alpha * t, beta, cp, (size_t)(i / N), (size_t)(i % N));
+            if (i / N >= M) {
+                epi.colsum[i % N] = alpha * t;
+            } else {
+                float *cp = C + (size_t)(i / N) * ldc + (i % N);
+                *cp = epilogue_value(epi, alpha * t, beta, cp, (size_t)(i / N), (size_t)(i % N));
+            }
         }
         __syncthreads();
     }
@@ -355,6 +399,12 @@ Split choose_split(uint32_t M, uint32_t N, uint32_t K) {
 
 }  // namespace
 
+MGGCN_API size_t mggcn_gemm_tn_colsum_workspace_bytes(uint32_t M, uint32_t N, uint32_t K) {
+    if (!M || !N || !K) return 0;
+    const Split s = choose_split(M, N, K);
+    return s.splits > 1 ? (size_t)s.splits * (M + 1) * N * sizeof(float) : 0;
+}
+
 MGGCN_API size_t mggcn_gemm_workspace_bytes(int trans_a, int trans_b, uint32_t M, uint32_t N, uint32_t K) {
     (void)trans_a; (void)trans_b;
     if (!M || !N || !K) return 0;
@@ -390,6 +440,22 @@ MGGCN_API void mggcn_gemm_bias_f32(mggcn_stream_t stream, int trans_a, int trans
     Epilogue e;
     e.bias = bias;
     gemm_dispatch(stream, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, workspace, workspace_bytes, e);
+}
+
+MGGCN_API void mggcn_gemm_tn_colsum_f32(mggcn_stream_t stream, uint32_t M, uint32_t N, uint32_t K, float alpha,
+                                        const float *A, size_t lda, const float *B, size_t ldb, float *C, size_t ldc,
+                                        float *colsum, void *workspace, size_t workspace_bytes) {
+    MGGCN_REQUIRE(colsum != nullptr, "mggcn_gemm_tn_colsum_f32 needs the column-sum output");
+    if (!N) return;
+    if (!K) {
+        MGGCN_CHECK_HIP(hipMemsetAsync(colsum, 0, (size_t)N * sizeof(float), as_stream(stream)));
+        if (M) gemm_dispatch(stream, 1, 0, M, N, 0, alpha, A, lda, B, ldb, 0.f, C, ldc, workspace, workspace_bytes, Epilogue{});
+        return;
+    }
+    MGGCN_REQUIRE(M > 0, "mggcn_gemm_tn_colsum_f32: M == 0");
+    Epilogue e;
+    e.colsum = colsum;
+    gemm_dispatch(stream, 1, 0, M, N, K, alpha, A, lda, B, ldb, 0.f, C, ldc, workspace, workspace_bytes, e);
 }
 
 MGGCN_API void mggcn_gemm_lrelu_bwd_f32(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N,
@@ -437,9 +503,10 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
     }
     const Split sp = choose_split(M, N, K);
     float *slab = nullptr;
+    const uint32_t slab_rows = M + (epi.colsum ? 1u : 0u);
     if (sp.splits > 1) {
-        MGGCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)sp.splits * M * N * sizeof(float),
-                      "split-K GEMM needs the workspace reported by mggcn_gemm_workspace_bytes");
+        MGGCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)sp.splits * slab_rows * N * sizeof(float),
+                      "split-K GEMM needs the workspace reported by mggcn_gemm_[tn_colsum_]workspace_bytes");
         slab = static_cast<float *>(workspace);
     }
     const bool a_vec = aligned16(A) && lda % 4 == 0;
@@ -470,7 +537,7 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
 #undef MGGCN_GEMM_LAUNCH
     MGGCN_CHECK_LAUNCH();
     if (sp.splits > 1) {
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(std::min<unsigned>((M * N + 31) / 32, 2048u)), dim3(256), 0,
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(std::min<unsigned>((slab_rows * N + 31) / 32, 2048u)), dim3(256), 0,
                            st, slab, sp.splits, M, N, alpha, beta, C, ldc, epi);
         MGGCN_CHECK_LAUNCH();
     }

@@ -708,8 +708,11 @@ class dist_row_linear:
             self.ones = dn_matrix(1, G.local.n(), device=ctx.device)
             ctx.fill(self.ones, 1.0)
         ctx.record(n + "1_0_matmul-gemm", 0)
-        ops.matmul(ctx, self.ones, G.local, self.G_b.local, 1.0, 0.0)
-        ops.matmul(ctx, self.X.local, G.local, self.G_W.local, 1.0, 0.0, True)
+        if self.fused:
+            ops.linear_backward_weights(ctx, self.X.local, G.local, self.G_W.local, self.G_b.local)
+        else:
+            ops.matmul(ctx, self.ones, G.local, self.G_b.local, 1.0, 0.0)
+            ops.matmul(ctx, self.X.local, G.local, self.G_W.local, 1.0, 0.0, True)
         # summed over ranks on the comm stream while the backward pass goes on; awaited by
         # finish_backward() (end of dist_gcn.backward) / adam_update
         self._grad_pending = dctx.all_reduce_sum_async(self.G_flat, 0)

@@ -108,9 +108,13 @@ class linear:
             self.ones = dn_matrix(1, G.n())
             ctx.fill(self.ones, 1.0)        # host-side std::fill in the reference (gcn.hpp:127-128)
         ctx.record(n + "1_0_matmul-gemm", 0)
-        ops.matmul(ctx, self.ones, G, self.G_b, 1.0, 0.0)
-        ctx.record(n + "1_1_matmul-gemm", 0)
-        ops.matmul(ctx, self.X, G, self.G_W, 1.0, 0.0, True)
+        if self.fused:                      # G_b rides on the B tiles of the G_W kernel: one pass over G
+            ctx.record(n + "1_1_matmul-gemm", 0)
+            ops.linear_backward_weights(ctx, self.X, G, self.G_W, self.G_b)
+        else:
+            ops.matmul(ctx, self.ones, G, self.G_b, 1.0, 0.0)
+            ctx.record(n + "1_1_matmul-gemm", 0)
+            ops.matmul(ctx, self.X, G, self.G_W, 1.0, 0.0, True)
         ctx.record(n + "1_2_matmul-gemm", 0)
         if self.backward_out and mask is not None:
             assert discard

@@ -154,9 +154,14 @@ public:
     void backward(context ctx, dn_t G, dn_t G_out, bool discard = true, const dn_t *mask = nullptr) {
         if (ones.n() != 1 || ones.m() != G.n()) { ones = dn_t(1, G.n()); ones.fill(1); }
         ctx.record(name + "1_0_matmul-gemm", 0);
-        matmul(ctx, ones, G, G_b, (r_t)1, (r_t)0);
-        ctx.record(name + "1_1_matmul-gemm", 0);
-        matmul(ctx, X, G, G_W, (r_t)1, (r_t)0, true);
+        if (fused) {                                  // G_b rides on the B tiles of the G_W kernel: one pass over G
+            ctx.record(name + "1_1_matmul-gemm", 0);
+            linear_backward_weights(ctx, X, G, G_W, G_b);
+        } else {
+            matmul(ctx, ones, G, G_b, (r_t)1, (r_t)0);
+            ctx.record(name + "1_1_matmul-gemm", 0);
+            matmul(ctx, X, G, G_W, (r_t)1, (r_t)0, true);
+        }
         ctx.record(name + "1_2_matmul-gemm", 0);
         if (backward_out && mask) matmul_lrelu_backward(ctx, G, W, *mask, G_out, (r_t)1, false, true);
         else if (backward_out) matmul(ctx, G, W, G_out, (r_t)1, discard ? (r_t)0 : (r_t)1, false, true);
@@ -263,6 +268,7 @@ public:
         const int cs = ctx.bcast_stream_id();
         ctx.record(name + "1_0_matmul-gemm", 0);
         for (std::size_t i = 0; i < ctx.size(); i++) {
+            if (fused) { linear_backward_weights(ctx[i], X[i], G[i], G_W[i], G_b[i]); continue; }
             matmul(ctx[i], ones[i], G[i], G_b[i], (r_t)1, (r_t)0);            // G_b = 1^T G      (local part)
             matmul(ctx[i], X[i], G[i], G_W[i], (r_t)1, (r_t)0, true);         // G_W = X^T G      (local part)
         }

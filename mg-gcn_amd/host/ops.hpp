@@ -81,6 +81,18 @@ void matmul_lrelu_backward(const context ctx, const dn_matrix<r_t> A, const dn_m
                              B.buffer(), B.m(), Z.buffer(), Z.m(), slope, C.buffer(), C.m(), ctx.gemm_workspace(ws), ws);
 }
 
+// G_W = X^T G and G_b = 1^T G in one pass over G (include/mggcn.h: mggcn_gemm_tn_colsum_f32; reference src/gcn.hpp:125-134)
+template <typename r_t>
+void linear_backward_weights(const context ctx, const dn_matrix<r_t> X, const dn_matrix<r_t> G, const dn_matrix<r_t> G_W,
+                             const dn_matrix<r_t> G_b) {
+    mggcn_require(X.n() == G.n() && G_W.n() == X.m() && G_W.m() == G.m() && G_b.n() == 1 && G_b.m() == G.m(),
+                  "linear_backward_weights: shape mismatch");
+    ctx.set();
+    const auto ws = mggcn_gemm_tn_colsum_workspace_bytes((uint32_t)X.m(), (uint32_t)G.m(), (uint32_t)X.n());
+    mggcn_gemm_tn_colsum_f32(ctx.stream(0), (uint32_t)X.m(), (uint32_t)G.m(), (uint32_t)X.n(), (r_t)1, X.buffer(), X.m(), G.buffer(),
+                             G.m(), G_W.buffer(), G_W.m(), G_b.buffer(), ctx.gemm_workspace(ws), ws);
+}
+
 // every (param, grad, m, v) quadruple of a model on one GPU as a device table: ONE Adam launch per epoch
 // (include/mggcn.h: mggcn_adam_multi_f32; reference src/gcn.hpp:146-172 runs 7 launches per layer)
 template <typename r_t>

@@ -139,6 +139,17 @@ def matmul_lrelu_backward(ctx: context, A: dn_matrix, B: dn_matrix, Z: dn_matrix
                                      ws.data_ptr() if ws is not None else None, ws_bytes)
 
 
+def linear_backward_weights(ctx: context, X: dn_matrix, G: dn_matrix, G_W: dn_matrix, G_b: dn_matrix) -> None:
+    """G_W = X^T G and G_b = 1^T G in ONE pass over G (the fused form of the two sgemms of linear::backward,
+    src/gcn.hpp:125-134): the column sums ride on the B tiles of the X^T G kernel."""
+    _req(X.n() == G.n() and G_W.shape() == (X.m(), G.m()) and G_b.shape() == (1, G.m()), "linear backward shape")
+    ctx.set()
+    ws_bytes = ctx.lib.mggcn_gemm_tn_colsum_workspace_bytes(X.m(), G.m(), X.n())
+    ws = ctx.workspace(ws_bytes)
+    ctx.lib.mggcn_gemm_tn_colsum_f32(ctx.stream(0), X.m(), G.m(), X.n(), 1.0, X.buffer(), X.m(), G.buffer(), G.m(),
+                                     G_W.buffer(), G_W.m(), G_b.buffer(), ws.data_ptr() if ws is not None else None, ws_bytes)
+
+
 def gather_rows(ctx: context, src: dn_matrix, indices, dst: dn_matrix, stream_id: int = 0) -> None:
     """dst[k, :] = src[indices[k], :] (halo pack; indices: device uint32 tensor viewed as int32 storage)"""
     n_idx = int(indices.numel())

@@ -493,3 +493,26 @@ def test_adam_multi_equals_per_tensor_fused(pkg, ctx):
         for a, b in zip(sets[0], sets[1]):
             for x, y in zip(a, b):
                 np.testing.assert_array_equal(x.numpy(), y.numpy())
+
+
+@pytest.mark.parametrize("n,din,dout", [(5000, 608, 128), (3001, 128, 41), (700, 16, 130), (9000, 128, 128), (40, 8, 5)])
+def test_gemm_tn_colsum_equals_the_two_gemms(pkg, oracle, ctx, n, din, dout):
+    """mggcn_gemm_tn_colsum_f32: G_W = X^T G and G_b = 1^T G in one pass (src/gcn.hpp:125-134) -- G_W BITWISE equal to
+    the plain X^T G GEMM (same tiles, same split-K), G_b equal to the ones-vector GEMM / the oracle at 1e-4, incl.
+    split-K shapes, two N-tiles (dout = 130) and ragged edges."""
+    rng = np.random.default_rng(n + din)
+    X = rng.standard_normal((n, din), dtype=np.float32)
+    G = rng.standard_normal((n, dout), dtype=np.float32)
+    Xd, Gd = pkg.dn_matrix.from_numpy(X), pkg.dn_matrix.from_numpy(G)
+    GW, Gb = pkg.dn_matrix(din, dout), pkg.dn_matrix(1, dout)
+    ctx.fill(GW, float("nan")); ctx.fill(Gb, float("nan"))
+    pkg.ops.linear_backward_weights(ctx, Xd, Gd, GW, Gb)
+    GW2, Gb2 = pkg.dn_matrix(din, dout), pkg.dn_matrix(1, dout)
+    pkg.matmul(ctx, Xd, Gd, GW2, 1.0, 0.0, True)
+    ones = pkg.dn_matrix(1, n); ctx.fill(ones, 1.0)
+    pkg.matmul(ctx, ones, Gd, Gb2, 1.0, 0.0)
+    ctx.sync()
+    np.testing.assert_array_equal(GW.numpy(), GW2.numpy())
+    want = oracle.gemm(np.ones((1, n), np.float32), G, f64acc=True)
+    assert relerr(Gb.numpy(), want) <= TOL and relerr(Gb2.numpy(), want) <= TOL
+    assert relerr(GW.numpy(), oracle.gemm(X, G, A_T=True, f64acc=True)) <= TOL
