@@ -112,6 +112,6 @@ def test_cli_row_partition_matches_dist_oracle(pkg, oracle, tmp_path, P, flags, 
     O = oracle.DistGcn(oracle.Csr(ip, ix, dv, n), [F, 16, 16, C], P)
     want = O.train_forward(X, Y)
     assert abs(got[0][1] - want[0]) <= 1e-4 * want[0] and abs(got[0][2] - want[1]) <= 3.0 / n
-    Cp = (C + P - 1) // P * P
-    text = (tmp_path / "csvs" / f"permuted_synth_{F}_16_16_{Cp}_{P}.csv").read_text()
+    # the file name carries the UNPADDED class count: it is built (src/main.cpp:100-111) before the padding (:135)
+    text = (tmp_path / "csvs" / f"permuted_synth_{F}_16_16_{C}_{P}.csv").read_text()
     assert re.search(rf"^0_{P - 1}_0_0_matmul-spmm:", text, re.M)          # per-rank timers "<epoch>_<rank>_<name>"
