@@ -542,7 +542,10 @@ MGGCN_API void mggcn_softmax_xent_fused_f32(mggcn_stream_t stream, float *H, con
                                             size_t n_rows, size_t m, float grad_scale, float *sums_device) {
     if (!n_rows) return;
     MGGCN_REQUIRE(m > 0 && m <= 64u * kXentMaxPerLane, "fused loss supports 1 <= m <= 1024 classes");
-    const dim3 grid(stream_grid(n_rows * 64)), block(256);
+    // two workgroups per CU: every workgroup ends with two float atomics on the SAME two words (the reported
+    // scalars), which execute one after the other at the memory side (~11 ns each) -- 2048 workgroups spent
+    // half the kernel queueing there; with several rows in flight per wave 8 waves per CU cover the latency
+    const dim3 grid(std::min<unsigned>(stream_grid(n_rows * 64), (unsigned)kNumCU * 2u)), block(256);
     hipStream_t st = as_stream(stream);
 #define MGGCN_XENT(K, R)                                                                              \
     hipLaunchKernelGGL((softmax_xent_fused_kernel<K, R>), grid, block, 0, st, H, Y, n_rows, m, grad_scale, \

@@ -574,6 +574,7 @@ class dist_sparse_linear:
         self.bcast = [bcast_buffer, bcast_buffer2]
         self.mode = mode
         self.plans = {}
+        self._views = {}
         self._halo_send = None
 
     def _plan(self, ctx: context, key, M: csr_matrix, d: int):
@@ -598,11 +599,18 @@ class dist_sparse_linear:
             # all-gathers are queued on the comm stream at once and land one after the other
             cb, K = A.chunk_bounds, len(A.remote_chunks)
             ctx.record(name + "0_matmul-bcast-start", cs)
+            # views of the receive buffer / of the shard per piece: built once per (matrix, operand, width) -- at
+            # P = 8 the host issues ~30 collectives + ~200 launches per epoch against ~2.4 ms of device work
+            vkey = (tag, B.local.buffer(), d)
+            views = self._views.get(vkey)
+            if views is None:
+                views = self._views[vkey] = [(dn_matrix(P * (cb[c + 1] - cb[c]), d, self.bcast[0][P * cb[c] * d:]),
+                                              B.local.t[cb[c]:cb[c + 1]]) for c in range(K)]
             pend, gathered = [], []
             for c in range(K):
-                g = dn_matrix(P * (cb[c + 1] - cb[c]), d, self.bcast[0][P * cb[c] * d:])
+                g, piece = views[c]
                 gathered.append(g)
-                pend.append(dctx.all_gather_rows(B.local.t[cb[c]:cb[c + 1]], g.t, cs))
+                pend.append(dctx.all_gather_rows(piece, g.t, cs))
             # local block first: no dependency on the exchange
             last_local = flags if P == 1 else 0
             ops._spmm(ctx, A.diag, B.local, C.local, self._plan(ctx, (tag, "diag"), A.diag, d), 1.0, beta,

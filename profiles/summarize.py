@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--main-kernel", default="spmm_vec4_kernel<32, 8, true>")
     ap.add_argument("--launches-per-unit", type=float, default=1,
                     help="kernel launches that make up ONE mggcn_spmm_csr_f32 call (sweep form: rounds)")
+    ap.add_argument("--narrow-kernel", default=None, help="second SpMM kernel (the logits-width form)")
+    ap.add_argument("--narrow-launches-per-unit", type=float, default=1)
     a = ap.parse_args()
 
     lines = []
@@ -69,13 +71,21 @@ def main():
         mk = pmc.get(a.main_kernel)
         if mk and "FETCH_SIZE" in mk and "WRITE_SIZE" in mk:
             traffic = int((2 * mk["FETCH_SIZE"] + mk["WRITE_SIZE"]) * 1024 * a.launches_per_unit)
-            json.dump({"kernel": a.main_kernel, "bytes_per_launch": traffic, "source": a.tag,
-                       "kernel_launches_per_spmm_call": a.launches_per_unit,
-                       "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 per kernel launch x launches per "
-                                  "SpMM call (gfx950: FETCH_SIZE halves wide coalesced reads)"},
-                      open(os.path.join(HERE, "spmm_hbm_traffic.json"), "w"), indent=1)
+            rec = {"kernel": a.main_kernel, "bytes_per_call": traffic, "source": f"profiles/{a.tag}_summary.md",
+                   "kernel_launches_per_spmm_call": a.launches_per_unit,
+                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 per kernel launch x launches per "
+                              "SpMM call (gfx950: FETCH_SIZE halves wide coalesced reads); separate --pmc passes"}
             lines.append(f"\nmain kernel `{a.main_kernel}`: traffic beyond L2 = {traffic / 1e9:.2f} GB per SpMM call "
                          f"({a.launches_per_unit} kernel launch(es) per call)")
+            nk = pmc.get(a.narrow_kernel) if a.narrow_kernel else None
+            if nk and "FETCH_SIZE" in nk and "WRITE_SIZE" in nk:
+                tn = int((2 * nk["FETCH_SIZE"] + nk["WRITE_SIZE"]) * 1024 * a.narrow_launches_per_unit)
+                rec["narrow_kernel"] = a.narrow_kernel
+                rec["bytes_per_call_narrow"] = tn
+                rec["kernel_launches_per_spmm_call_narrow"] = a.narrow_launches_per_unit
+                lines.append(f"narrow kernel `{a.narrow_kernel}`: traffic beyond L2 = {tn / 1e9:.2f} GB per SpMM call "
+                             f"({a.narrow_launches_per_unit} kernel launch(es) per call)")
+            json.dump(rec, open(os.path.join(HERE, "spmm_hbm_traffic.json"), "w"), indent=1)
     out = os.path.join(HERE, f"{a.tag}_summary.md")
     open(out, "w").write("\n".join(lines) + "\n")
     print(open(out).read())
