@@ -127,6 +127,13 @@ uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan);
 uint32_t mggcn_spmm_plan_num_sweep_tasks(const mggcn_spmm_plan *plan); /* 0: no sweep form */
 uint32_t mggcn_spmm_plan_num_launches(const mggcn_spmm_plan *plan, uint32_t d); /* kernel launches per SpMM call at width d */
 size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan);
+uint32_t mggcn_spmm_plan_num_slices(const mggcn_spmm_plan *plan);      /* column slices of the sweep form (0: none) */
+/* diagnostics: with MGGCN_SPMM_STAMPS=1 in the environment at plan creation the d >= 96 sweep kernel records, per
+ * one-wave task of column slice `slice`, {start, end} on the 100 MHz constant clock and {HW_ID << 32 | blockIdx << 4 | XCC id} of
+ * its LAST launch; this copies them out (3 x u64 per task, blocking) and returns the task count.  Never set in a
+ * timed run. */
+uint32_t mggcn_spmm_plan_read_stamps(const mggcn_spmm_plan *plan, uint32_t slice, uint64_t *host_out,
+                                     uint32_t capacity_tasks);
 
 /* flags */
 #define MGGCN_SPMM_DEFAULT 0u

@@ -54,6 +54,8 @@ PROTOTYPES = {
     "mggcn_spmm_plan_num_sweep_tasks": (c_uint32, [vp]),
     "mggcn_spmm_plan_num_launches": (c_uint32, [vp, c_uint32]),
     "mggcn_spmm_plan_bytes": (c_size_t, [vp]),
+    "mggcn_spmm_plan_num_slices": (c_uint32, [vp]),
+    "mggcn_spmm_plan_read_stamps": (c_uint32, [vp, c_uint32, vp, c_uint32]),
     "mggcn_spmm_csr_f32": (None, [vp, vp, c_uint32, c_uint32, vp, vp, vp, vp, c_size_t, vp, c_size_t,
                                   c_uint32, c_float, c_float, c_uint32, c_float]),
     "mggcn_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_uint32, c_uint32, c_uint32]),

@@ -440,6 +440,14 @@ MGGCN_API size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan) {
     for (auto *sp : plan->sweeps) b += sweep_plan_bytes(sp);
     return b;
 }
+MGGCN_API uint32_t mggcn_spmm_plan_read_stamps(const mggcn_spmm_plan *plan, uint32_t slice, uint64_t *host_out,
+                                               uint32_t capacity_tasks) {
+    if (!plan || slice >= plan->sweeps.size()) return 0;
+    return sweep_plan_read_stamps(plan->sweeps[slice], reinterpret_cast<unsigned long long *>(host_out), capacity_tasks);
+}
+
+MGGCN_API uint32_t mggcn_spmm_plan_num_slices(const mggcn_spmm_plan *plan) { return plan ? (uint32_t)plan->sweeps.size() : 0; }
+
 MGGCN_API uint32_t mggcn_spmm_plan_num_launches(const mggcn_spmm_plan *plan, uint32_t d) {
     // kernel launches one mggcn_spmm_csr_f32 call makes with this plan at width d (aligned operands assumed)
     if (!plan) return 1;

@@ -22,6 +22,7 @@ void sweep_plan_destroy(SweepPlan *p);
 size_t sweep_plan_bytes(const SweepPlan *p);
 uint32_t sweep_plan_tasks(const SweepPlan *p);
 uint32_t sweep_plan_split_rows(const SweepPlan *p);
+uint32_t sweep_plan_read_stamps(const SweepPlan *p, unsigned long long *host_out, uint32_t capacity_tasks);
 uint32_t sweep_plan_launches(const SweepPlan *p, uint32_t d);   // kernel launches of one sweep_launch at width d
 // true if this (d, alignment) combination is served by the sweep kernels
 bool sweep_supports(const SweepPlan *p, uint32_t d, size_t ldb, size_t ldc, const void *B, const void *C);

@@ -61,6 +61,26 @@ constexpr uint32_t kColMask = (1u << kColBits) - 1;
 constexpr uint32_t kSlotFlag = 0x80000000u;
 constexpr uint32_t kRunFlag = 0x80000000u;     // entry bit 31: first entry of a (panel,row) run; bits 30..27: row
 constexpr int kWavesPerBlock = 4;
+// internal launch flags (never part of the ABI's flags): bit 8 = rotate the wave priority, bits 12..15 = log2 of the
+// rotation period in entries
+constexpr uint32_t kFlagPrioRotate = 0x100u;
+constexpr uint32_t kPrioShiftPos = 12;
+
+// Priority rotation.  The four waves that share a SIMD are served oldest first: measured per hardware wave slot
+// (= blockIdx / 256: blocks are dealt one per CU per "layer"; profiles/experiments/wave_spread.py) equal tasks took
+// 305 / 308 / 317 / 330 us -- the youngest wave 8 % slower all launch long, so the waves spread over +-6 % of the
+// column slice (two panels: the resident window outgrows the L2) and every launch ended in an 8 % tail.  Every
+// 2^shift entries each wave moves one priority level on (level = slot + phase mod 4): every wave spends the same share
+// of the launch at every level -> 299 / 298 / 296 / 300 us, d = 128 SpMM 2.59 -> 2.44 ms forward, 2.73 -> 2.52 backward
+// (profiles/experiments/prio_rotate_r02.log).  Speed only: results never depend on it.
+__device__ __forceinline__ void rotate_priority(uint32_t slot, uint32_t phase) {
+    switch ((slot + phase) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
 
 struct SweepTask {
     uint32_t beg, end;   // entry range
@@ -333,17 +353,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
     const SweepTask *__restrict__ tasks, uint32_t task0, uint32_t n_launch,
     const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
     const float *__restrict__ B, uint32_t b_bytes, uint32_t row_bytes, float *__restrict__ C, size_t ldc,
-    float *__restrict__ partial, uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
+    float *__restrict__ partial, uint32_t d, float alpha, float beta, uint32_t flags, float slope,
+    unsigned long long *__restrict__ stamps) {
     const int lane = threadIdx.x & 63;
     const uint32_t wib = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
     const uint32_t local = blockIdx.x * kWavesPerBlock + wib;
     if (local >= n_launch) return;                    // no barriers: waves are independent
     const uint32_t t = task0 + local;
     const SweepTask task = tasks[t];
+    // diagnostics (MGGCN_SPMM_STAMPS=1, never in a timed run): start / end of every wave on the 100 MHz constant clock
+    const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, b_bytes, 0x00020000);
     const uint32_t sub = lane & 31;
     const uint32_t hmask = (lane & 32) ? 0xFFFFFFFFu : 0u;     // upper half-wave takes the pair's 2nd entry
+    const uint32_t prio_slot = blockIdx.x / kNumCU;            // blocks are dealt one per CU per "layer": layer = hardware wave slot
+    const uint32_t prio_shift = (flags >> kPrioShiftPos) & 15u, prio_mask = (1u << prio_shift) - 1u;
 
     for (uint32_t col0 = 0; col0 < d; col0 += 128) {
         const uint32_t col = col0 + sub * 4;
@@ -357,6 +382,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
         if (task.beg < task.end) {
             EntryBatch cur = load_batch(entries, task.beg);
             for (uint32_t e = task.beg; e < task.end; e += 8) {
+                if ((flags & kFlagPrioRotate) && ((e - task.beg) & prio_mask) == 0)
+                    rotate_priority(prio_slot, (e - task.beg) >> prio_shift);
                 const uint32_t e_next = e + 8 < task.end ? e + 8 : e;
                 const EntryBatch nxt = load_batch(entries, e_next);
                 f32x4_t b[4];
@@ -428,6 +455,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
             }
         };
         MGGCN_PLANES_EMIT_FOURS(emit4)
+    }
+    if (stamps) {                                       // wave-uniform
+        uint32_t xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));      // wave slot / SIMD / CU / SE of this wave
+        if (lane == 0) {
+            stamps[3 * (size_t)t + 0] = t_start;
+            stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            stamps[3 * (size_t)t + 2] = ((unsigned long long)hw << 32) | ((unsigned long long)(blockIdx.x & 0xFFFFF) << 4) | (xcc & 0xF);
+        }
     }
 }
 
@@ -522,7 +559,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
         const uint32_t n_chunks = (n_ent + CH - 1) / CH;  // the plan leaves a chunk of slack after the last task
         ring[wib][0][lane] = stream[0];
         uint4 pre = stream[n_chunks > 1 ? CH / 2 : 0];
+        const uint32_t prio_slot = blockIdx.x / kNumCU;
+        const uint32_t prio_shift = (flags >> kPrioShiftPos) & 15u;          // in chunks of CH (~128) entries here
         for (uint32_t c = 0; c < n_chunks; c++) {
+            if ((flags & kFlagPrioRotate) && (c & ((1u << prio_shift) - 1u)) == 0) rotate_priority(prio_slot, c >> prio_shift);
             ring[wib][(c + 1) & 1][lane] = pre;           // chunk c+1 (slot last read during chunk c-1)
             pre = stream[(size_t)(CH / 2) * (c + 2 < n_chunks ? c + 2 : c)];
             __builtin_amdgcn_wave_barrier();
@@ -645,6 +685,7 @@ struct SweepPlan {
     uint32_t *d_task_rows = nullptr;
     SweepSplitRow *d_split = nullptr;
     float *d_partial = nullptr;
+    unsigned long long *d_stamps = nullptr;   // diagnostics: 3 words per task (MGGCN_SPMM_STAMPS=1)
     size_t bytes = 0;
 };
 
@@ -870,6 +911,10 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
         MGGCN_CHECK_HIP(hipMemcpy(p->d_split, split_rows.data(), sb, hipMemcpyHostToDevice));
     }
     if (pb) MGGCN_CHECK_HIP(hipMalloc(&p->d_partial, pb));
+    if (env_u32("MGGCN_SPMM_STAMPS", 0u)) {
+        MGGCN_CHECK_HIP(hipMalloc(&p->d_stamps, (size_t)T * 3 * sizeof(unsigned long long)));
+        MGGCN_CHECK_HIP(hipMemset(p->d_stamps, 0, (size_t)T * 3 * sizeof(unsigned long long)));
+    }
     p->bytes = tb + eb + rb + sb + pb;
     return p;
 }
@@ -881,12 +926,21 @@ void sweep_plan_destroy(SweepPlan *p) {
     if (p->d_task_rows) MGGCN_CHECK_HIP(hipFree(p->d_task_rows));
     if (p->d_split) MGGCN_CHECK_HIP(hipFree(p->d_split));
     if (p->d_partial) MGGCN_CHECK_HIP(hipFree(p->d_partial));
+    if (p->d_stamps) MGGCN_CHECK_HIP(hipFree(p->d_stamps));
     delete p;
 }
 
 size_t sweep_plan_bytes(const SweepPlan *p) { return p ? p->bytes : 0; }
 uint32_t sweep_plan_tasks(const SweepPlan *p) { return p ? p->n_tasks : 0; }
 uint32_t sweep_plan_split_rows(const SweepPlan *p) { return p ? p->n_split_rows : 0; }
+
+uint32_t sweep_plan_read_stamps(const SweepPlan *p, unsigned long long *host_out, uint32_t capacity_tasks) {
+    if (!p || !p->d_stamps) return 0;
+    const uint32_t n = std::min(p->n_tasks, capacity_tasks);
+    MGGCN_CHECK_HIP(hipDeviceSynchronize());
+    MGGCN_CHECK_HIP(hipMemcpy(host_out, p->d_stamps, (size_t)n * 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return n;
+}
 
 uint32_t sweep_plan_launches(const SweepPlan *p, uint32_t d) {
     if (!p) return 0;
@@ -943,9 +997,13 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
     for (uint32_t t0 = 0; t0 < p->n_tasks; t0 += per_launch) {
         const uint32_t n_launch = std::min(per_launch, p->n_tasks - t0);
         const dim3 grid((n_launch + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+        // priority rotation (float4 kernels; see rotate_priority): period 2^8 entries / every chunk of the narrow stream
+        const uint32_t rot = env_u32("MGGCN_SPMM_PRIO_ROTATE", 1u) ? kFlagPrioRotate : 0u;
+        const uint32_t wide_flags = (flags & 0xFFu) | rot | (std::min(env_u32("MGGCN_SPMM_PRIO_SHIFT", 8u), 15u) << kPrioShiftPos);
+        const uint32_t narrow_flags = (flags & 0xFFu) | rot | (std::min(env_u32("MGGCN_SPMM_PRIO_SHIFT_NARROW", 1u), 15u) << kPrioShiftPos);
 #define MGGCN_LAUNCH_NARROW(L)                                                                             \
     hipLaunchKernelGGL((spmm_sweep_quad_lds_kernel<L>), grid, block, 0, st, p->d_tasks, t0, n_launch, p->d_entries, \
-                       p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d, alpha, beta, flags, slope)
+                       p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d, alpha, beta, narrow_flags, slope)
         if (quad) {
             if (p->lpe == 4) MGGCN_LAUNCH_NARROW(4);
             else if (p->lpe == 8) MGGCN_LAUNCH_NARROW(8);
@@ -956,7 +1014,7 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
         else if (vec4)
             hipLaunchKernelGGL(spmm_sweep_pair_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
-                               alpha, beta, flags, slope);
+                               alpha, beta, wide_flags, slope, p->d_stamps);
         else if (vec2)
             hipLaunchKernelGGL((spmm_sweep_kernel<2>), grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,

@@ -40,7 +40,7 @@ for order in ("as generated", "degree-sorted"):
         print(f"permute on host {time.time() - t:.1f} s", flush=True)
     A.normalize(True)
     A_T = A.transpose()
-    for env in ({}, {"MGGCN_SPMM_PANEL_ROWS": "8192"}, {"MGGCN_SPMM_PANEL_ROWS": "4096"}, {"MGGCN_SPMM_SLICE_MIB": "128"}):
+    for env in ([{}] if os.environ.get("EXP_QUICK") else [{}, {"MGGCN_SPMM_PANEL_ROWS": "8192"}, {"MGGCN_SPMM_PANEL_ROWS": "4096"}, {"MGGCN_SPMM_SLICE_MIB": "128"}]):
         for k in ("MGGCN_SPMM_PANEL_ROWS", "MGGCN_SPMM_SLICE_MIB"):
             os.environ.pop(k, None)
         os.environ.update(env)
