@@ -335,7 +335,8 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         // Column slices: the sweep keeps the active part of B in L2 only while the waves stay
         // within a few MiB of each other; their drift grows with the length of the sweep
         // (measured: a 32 MiB extent runs at the in-L2 rate, the full 114 MiB Reddit extent 25 %
-        // slower; with the six-instruction run fold 64 MiB slices edge out 32: 2.69 vs 2.73 ms).
+        // slower; with the six-instruction run fold 64 MiB slices edge out 32: 2.69 vs 2.73 ms; with the priority
+        // rotation of spmm_sweep.hip 64 MiB is the optimum for the backward matrix too: 2.52 -> 2.40 ms).
         // So B is cut into slices of <= MGGCN_SPMM_SLICE_MIB (at 512-byte rows) and
         // C = beta C + alpha sum_s A[:, slice s] B is evaluated slice after slice: every launch
         // boundary re-synchronises the chip.  Costs one extra read+write of C per extra slice.
@@ -360,7 +361,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         }
         if (const char *hc = std::getenv("MGGCN_SPMM_HOT_COLUMNS")) hot_columns = std::atoi(hc) != 0;
         const uint64_t slice_rows = std::max<uint64_t>(
-            64, env_u32("MGGCN_SPMM_SLICE_ROWS", (uint32_t)(((uint64_t)env_u32("MGGCN_SPMM_SLICE_MIB", (hot_columns || narrow) ? 64u : 32u) << 20) / hint_bytes)));   // tests set ROWS
+            64, env_u32("MGGCN_SPMM_SLICE_ROWS", (uint32_t)(((uint64_t)env_u32("MGGCN_SPMM_SLICE_MIB", 64u) << 20) / hint_bytes)));   // tests set ROWS
         uint32_t S = (uint32_t)std::max<uint64_t>(1, ((uint64_t)n_cols + slice_rows - 1) / slice_rows);
         const uint64_t total_nnz = n_rows ? (uint64_t)host_indptr[n_rows] - host_indptr[0] : 0;
         // The sweep pays only for DENSE rows: its unit of work is a (panel,row) run, and a graph

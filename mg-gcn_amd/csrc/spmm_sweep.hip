@@ -672,7 +672,11 @@ uint32_t sweep_panel_rows(uint32_t d_hint, bool hot_columns) {
         const uint32_t rows = std::max(1024u, (3u << 19) / pitch / 1024u * 1024u);
         return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS_NARROW", rows));
     }
-    return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", hot_columns ? 6144u : 4096u));
+    // Round 1 (no priority rotation): 6144 rows for the forward matrix (hot columns), 4096 for the backward one.  With the
+    // waves of a SIMD equalised (rotate_priority) 4096-row panels (2 MiB) win on both: forward 2.45 -> 2.42 ms, and the
+    // backward matrix no longer needs 32-MiB slices (profiles/experiments/retune_after_rotation_r02.log).
+    (void)hot_columns;
+    return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 4096u));
 }
 
 struct SweepPlan {
