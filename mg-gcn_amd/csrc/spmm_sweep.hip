@@ -354,21 +354,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
     const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
     const float *__restrict__ B, uint32_t b_bytes, uint32_t row_bytes, float *__restrict__ C, size_t ldc,
     float *__restrict__ partial, uint32_t d, float alpha, float beta, uint32_t flags, float slope,
-    unsigned long long *__restrict__ stamps) {
+    unsigned long long *__restrict__ stamps, uint32_t wave_stride) {
     const int lane = threadIdx.x & 63;
     const uint32_t wib = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
     const uint32_t local = blockIdx.x * kWavesPerBlock + wib;
     if (local >= n_launch) return;                    // no barriers: waves are independent
-    const uint32_t t = task0 + local;
-    const SweepTask task = tasks[t];
-    // diagnostics (MGGCN_SPMM_STAMPS=1, never in a timed run): start / end of every wave on the 100 MHz constant clock
-    const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, b_bytes, 0x00020000);
     const uint32_t sub = lane & 31;
     const uint32_t hmask = (lane & 32) ? 0xFFFFFFFFu : 0u;     // upper half-wave takes the pair's 2nd entry
     const uint32_t prio_slot = blockIdx.x / kNumCU;            // blocks are dealt one per CU per "layer": layer = hardware wave slot
     const uint32_t prio_shift = (flags >> kPrioShiftPos) & 15u, prio_mask = (1u << prio_shift) - 1u;
+
+    // one task per wave per launch by default (wave_stride >= n_launch); MGGCN_SPMM_TASKS_PER_WAVE > 1 lets a wave walk
+    // several tasks of the round table in one launch (experiment: fewer launch tails against longer unsynchronised runs)
+    for (uint32_t tl = local; tl < n_launch; tl += wave_stride) {
+    const uint32_t t = task0 + tl;
+    const SweepTask task = tasks[t];
+    // diagnostics (MGGCN_SPMM_STAMPS=1, never in a timed run): start / end of every wave on the 100 MHz constant clock
+    const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     for (uint32_t col0 = 0; col0 < d; col0 += 128) {
         const uint32_t col = col0 + sub * 4;
@@ -466,6 +470,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
             stamps[3 * (size_t)t + 2] = ((unsigned long long)hw << 32) | ((unsigned long long)(blockIdx.x & 0xFFFFF) << 4) | (xcc & 0xF);
         }
     }
+    }   // tasks of this wave
 }
 
 // ---------------------------------------------------------------------------------------
@@ -951,7 +956,8 @@ uint32_t sweep_plan_launches(const SweepPlan *p, uint32_t d) {
     const bool quad = p->lpe && d <= 4 * p->lpe;
     const bool vec4 = p->run_pad % 2 == 0 && d >= 96 && d % 4 == 0;
     const bool vec2 = d > 64 && d % 2 == 0;
-    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
+    const uint32_t tpw = (vec4 && !quad) ? std::max(1u, env_u32("MGGCN_SPMM_TASKS_PER_WAVE", 1u)) : 1u;
+    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks * tpw : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
     return (p->n_tasks + per_launch - 1) / per_launch + (p->n_split_rows ? 1u : 0u);
 }
 
@@ -997,10 +1003,12 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
     // waves per CU; six blocks per launch left a third of the waves queued behind the others and out
     // of step: d = 41 1.64 / 1.71 ms against 1.52 / 1.55).  The one-column-per-lane kernels (56 VGPRs)
     // are instruction-bound and take six blocks per CU (d = 41: 2.4 -> 2.0 ms).
-    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
+    const uint32_t tpw = (vec4 && !quad) ? std::max(1u, env_u32("MGGCN_SPMM_TASKS_PER_WAVE", 1u)) : 1u;
+    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks * tpw : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
     for (uint32_t t0 = 0; t0 < p->n_tasks; t0 += per_launch) {
         const uint32_t n_launch = std::min(per_launch, p->n_tasks - t0);
-        const dim3 grid((n_launch + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
+        const uint32_t n_waves = tpw > 1 ? std::min(n_launch, p->round_tasks) : n_launch;
+        const dim3 grid((n_waves + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
         // priority rotation (float4 kernels; see rotate_priority): period 2^8 entries / every chunk of the narrow stream
         const uint32_t rot = env_u32("MGGCN_SPMM_PRIO_ROTATE", 1u) ? kFlagPrioRotate : 0u;
         const uint32_t wide_flags = (flags & 0xFFu) | rot | (std::min(env_u32("MGGCN_SPMM_PRIO_SHIFT", 8u), 15u) << kPrioShiftPos);
@@ -1018,7 +1026,7 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
         else if (vec4)
             hipLaunchKernelGGL(spmm_sweep_pair_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
-                               alpha, beta, wide_flags, slope, p->d_stamps);
+                               alpha, beta, wide_flags, slope, p->d_stamps, tpw > 1 ? p->round_tasks : n_launch);
         else if (vec2)
             hipLaunchKernelGGL((spmm_sweep_kernel<2>), grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
