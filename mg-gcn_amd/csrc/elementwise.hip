@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include <map>
+#include <type_traits>
 #include <mutex>
 #include <utility>
 
@@ -152,6 +153,25 @@ __global__ __launch_bounds__(256) void max_rows_kernel(const float *__restrict__
 }
 
 // argmax, first maximum wins           reference src/cuda_utils.cu:119-133
+// Wave-wide reductions on the DPP path (no LDS): four in-row steps (quad swaps, half-row and row mirrors) leave every
+// lane of a 16-lane row with its row's result, four v_readlane bring the row results together.  hipcc lowers
+// __shfl_xor to ds_bpermute_b32, an LDS-crossbar instruction: the fused loss kernel spent its time there (~30 per row).
+template <typename Op>
+__device__ __forceinline__ float wave_reduce_dpp(float v, Op op) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));     // quad_perm [1,0,3,2]
+    v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));     // quad_perm [2,3,0,1]
+    v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));    // row_half_mirror
+    v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));    // row_mirror
+    const float r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
+    const float r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return op(op(r0, r1), op(r2, r3));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) { return wave_reduce_dpp(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float wave_max_dpp(float v) { return wave_reduce_dpp(v, [](float a, float b) { return fmaxf(a, b); }); }
+
 __device__ __forceinline__ void argmax_combine(float &v, uint32_t &i, float ov, uint32_t oi) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
@@ -291,18 +311,16 @@ __global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restri
         for (int q = 0; q < R; q++) {
             const size_t r = r0 + (size_t)q * wstride;
             if (r >= n_rows) break;                       // wave-uniform
+            // row maximum (wave-uniform) and the FIRST column holding it (strict `<` of the reference, cuda_utils.cu:126)
             float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < K; k++) mx = fmaxf(mx, x[q][k]);
+            mx = wave_max_dpp(mx);
             uint32_t idx = 0xFFFFFFFFu;
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const size_t c = (size_t)lane + 64u * k;
-                if (x[q][k] > mx) { mx = x[q][k]; idx = (uint32_t)c; }
-            }
-#pragma unroll
-            for (int off = 32; off; off >>= 1) {
-                const float ov = __shfl_xor(mx, off);
-                const uint32_t oi = __shfl_xor(idx, off);
-                argmax_combine(mx, idx, ov, oi);
+            for (int k = K - 1; k >= 0; k--) {
+                const unsigned long long hit = __ballot(x[q][k] == mx && (size_t)lane + 64u * k < m);
+                if (hit) idx = (uint32_t)__builtin_ctzll(hit) + 64u * (uint32_t)k;        // lower k = lower columns: last writer wins
             }
             float sum = 0.f;
 #pragma unroll
@@ -311,19 +329,23 @@ __global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restri
                 x[q][k] = c < m ? expf(x[q][k] - mx) : 0.f;
                 sum += x[q][k];
             }
-            sum = wave_sum(sum);
-            float py = 0.f;
+            sum = wave_sum_dpp(sum);
+            float py = 0.f;                                    // p_y: read from the lane that holds column y
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const size_t c = (size_t)lane + 64u * k;
                 if (c < m) {
                     const float o = x[q][k] / sum;
                     const bool hit = (int32_t)c == y[q];
-                    if (hit) py = o;
                     H[r * m + c] = (hit ? o - 1.f : o) * grad_scale;
+                    x[q][k] = o;
                 }
             }
-            py = wave_sum(py);  // exactly one lane holds p_y
+            if (y[q] >= 0 && (size_t)y[q] < m) {               // wave-uniform
+#pragma unroll
+                for (int k = 0; k < K; k++)
+                    if ((y[q] >> 6) == k) py = __builtin_amdgcn_readlane(x[q][k], y[q] & 63);
+            }
             if (lane == 0) {
                 loss_acc += fabsf(logf(py));
                 // argmax of the softmax output == argmax of the logits (exp is monotone);
@@ -542,10 +564,9 @@ MGGCN_API void mggcn_softmax_xent_fused_f32(mggcn_stream_t stream, float *H, con
                                             size_t n_rows, size_t m, float grad_scale, float *sums_device) {
     if (!n_rows) return;
     MGGCN_REQUIRE(m > 0 && m <= 64u * kXentMaxPerLane, "fused loss supports 1 <= m <= 1024 classes");
-    // two workgroups per CU: every workgroup ends with two float atomics on the SAME two words (the reported
-    // scalars), which execute one after the other at the memory side (~11 ns each) -- 2048 workgroups spent
-    // half the kernel queueing there; with several rows in flight per wave 8 waves per CU cover the latency
-    const dim3 grid(std::min<unsigned>(stream_grid(n_rows * 64), (unsigned)kNumCU * 2u)), block(256);
+    // (tried: two workgroups per CU to thin out the two contended scalar atomics at the end of every workgroup --
+    //  105 -> 145 us: the pass wants the occupancy; its cost is the ~30 ds_bpermute wave-reductions per row)
+    const dim3 grid(stream_grid(n_rows * 64)), block(256);
     hipStream_t st = as_stream(stream);
 #define MGGCN_XENT(K, R)                                                                              \
     hipLaunchKernelGGL((softmax_xent_fused_kernel<K, R>), grid, block, 0, st, H, Y, n_rows, m, grad_scale, \

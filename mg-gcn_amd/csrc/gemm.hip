@@ -44,6 +44,7 @@ struct Epilogue {
     size_t ldz = 0;
     float slope = 0.f;
     float *colsum = nullptr;         // also 1^T op(B) -> colsum[N]   (mggcn_gemm_tn_colsum_f32; B stored [K][N])
+    int prio = 0;                    // experiment (MGGCN_GEMM_PRIO): 1 = memory phases at s_setprio 1, 2 = MFMA phase at 1
 };
 
 __device__ __forceinline__ float epilogue_value(const Epilogue &e, float av, float beta, const float *cp, size_t row, size_t col) {
@@ -186,10 +187,13 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(
     int cur = 0;
     for (long long k0 = k_begin; k0 < k_end; k0 += BK, cur ^= 1) {
         const bool more = k0 + BK < k_end;
+        if (epi.prio == 1) __builtin_amdgcn_s_setprio(1);
         if (more) {                      // global loads of the next K-step fly under the MFMAs
             sa.load(A, lda, m0, M, k0 + BK, k_end, a_vec, tid);
             sb.load(B, ldb, n0, N, k0 + BK, k_end, b_vec, tid);
         }
+        if (epi.prio == 1) __builtin_amdgcn_s_setprio(0);
+        if (epi.prio == 2) __builtin_amdgcn_s_setprio(1);
         const float *as = As[cur], *bs = Bs[cur];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; kk++) {
@@ -206,11 +210,14 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(
                 for (int j = 0; j < NI; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (epi.prio == 2) __builtin_amdgcn_s_setprio(0);
+        if (epi.prio == 1) __builtin_amdgcn_s_setprio(1);
         if (more) {                      // the other buffer: nobody reads it until the barrier below
             add_colsum();
             sa.store(As[cur ^ 1], tid);
             sb.store(Bs[cur ^ 1], tid);
         }
+        if (epi.prio == 1) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
     if constexpr (!B_KCONTIG) {
@@ -474,8 +481,11 @@ MGGCN_API void mggcn_gemm_lrelu_bwd_f32(mggcn_stream_t stream, int trans_a, int 
 namespace {
 void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, uint32_t N, uint32_t K, float alpha,
                    const float *A, size_t lda, const float *B, size_t ldb, float beta, float *C, size_t ldc,
-                   void *workspace, size_t workspace_bytes, const Epilogue &epi) {
+                   void *workspace, size_t workspace_bytes, const Epilogue &epi_in) {
     if (!M || !N) return;
+    Epilogue epi = epi_in;
+    static const int prio_env = [] { const char *e = std::getenv("MGGCN_GEMM_PRIO"); return e ? std::atoi(e) : 0; }();
+    epi.prio = prio_env;
     hipStream_t st = as_stream(stream);
     MGGCN_REQUIRE(C != nullptr && ldc >= N, "bad C / ldc");
     if (!K) {
