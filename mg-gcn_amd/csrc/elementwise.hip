@@ -165,8 +165,9 @@ __device__ __forceinline__ float wave_reduce_dpp(float v, Op op) {
     v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));     // quad_perm [2,3,0,1]
     v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));    // row_half_mirror
     v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));    // row_mirror
-    const float r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16);
-    const float r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    // (the builtin is typed int: a float argument would be CONVERTED, not re-interpreted)
+    auto lane_f = [](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
+    const float r0 = lane_f(v, 0), r1 = lane_f(v, 16), r2 = lane_f(v, 32), r3 = lane_f(v, 48);
     return op(op(r0, r1), op(r2, r3));
 }
 __device__ __forceinline__ float wave_sum_dpp(float v) { return wave_reduce_dpp(v, [](float a, float b) { return a + b; }); }
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restri
             if (y[q] >= 0 && (size_t)y[q] < m) {               // wave-uniform
 #pragma unroll
                 for (int k = 0; k < K; k++)
-                    if ((y[q] >> 6) == k) py = __builtin_amdgcn_readlane(x[q][k], y[q] & 63);
+                    if ((y[q] >> 6) == k)
+                        py = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[q][k]), y[q] & 63));
             }
             if (lane == 0) {
                 loss_acc += fabsf(logf(py));
