@@ -232,6 +232,12 @@ def test_reserved_accumulator_registers_are_left_alone_by_the_compiler(tmp_path)
             if not inside and st and not st.startswith((".", ";")) and re.search(r"\bm0\b", st.split(";")[0]):
                 raise AssertionError(f"{kern}: compiler-generated instruction uses m0: {st}")
     assert seen == {"pair", "quad"}
+    # the wave-priority rotation (rotate_priority: all four s_setprio levels) is compiled into both kernel families
+    for fam in ("spmm_sweep_pair_kernel", "spmm_sweep_quad_lds_kernel"):
+        bodies = re.findall(r"^(_Z\S*%s[^\s:]*):[^\n]*\n(.*?)s_endpgm" % fam, text, flags=re.S | re.M)
+        assert bodies, fam
+        for name, body in bodies:
+            assert {int(x) for x in re.findall(r"s_setprio (\d)", body)} == {0, 1, 2, 3}, name
     # metadata of EVERY instantiation (pair + quad_lds<4|8|12|16>): 128 VGPRs, no AGPRs (a spill of the
     # reserved planes would go there first), no scratch
     meta = text[text.index("amdhsa.kernels"):]
