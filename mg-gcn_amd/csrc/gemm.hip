@@ -16,19 +16,37 @@
 // (no TF32-style truncation exists on gfx950), i.e. at least as accurate as the
 // reference's cublasSgemm.
 //
-// Tile anatomy (256 threads = 4 wave64):
-//   BN = 128: waves 2(M) x 2(N), each 64 x 64 = 2x2 MFMA blocks  (64 acc VGPRs)
-//   BN =  64: waves 4(M) x 1(N), each 32 x 64 = 1x2 MFMA blocks  (32 acc VGPRs)
-//   LDS: As[32][BM+pad] + Bs[32][BN+pad] fp32, k-major so the MFMA operand read
-//        (lane l -> row l&31, k l>>5) is a conflict-free ds_read_b32.
-//   Global->LDS goes through registers, prefetched one K-step ahead.
+// Tile anatomy (512 threads = 8 wave64, two workgroups per CU = 4 waves per SIMD, <= 128 VGPRs):
+//   BN = 128: waves 4(M) x 2(N), each 32 x 64 = 1x2 MFMA blocks  (32 acc VGPRs)
+//   BN =  64: waves 4(M) x 2(N), each 32 x 32 = 1x1 MFMA block   (16 acc VGPRs)
+//   LDS: two buffers of As[32][BM+pad] + Bs[32][BN+pad] fp32, k-major so the MFMA operand read
+//        (lane l -> row l&31, k l>>5) is a conflict-free ds_read_b32; ONE barrier per K-step.
+//   Global->LDS goes through two register sets: tile t+2 is requested while tile t is multiplied and
+//   tile t+1 (requested a step earlier) is written to the other LDS buffer between the two halves of
+//   the step's MFMAs.  Loads are branch-free (clamped addresses; see Stager).
 //   Operands whose K index is the contiguous one (A not transposed, B transposed)
 //   are transposed on the LDS write; the others are copied with 16-byte stores.
 // Split-K partial tiles land in a caller-provided slab and are summed in split
 // order by a second kernel (reproducible; no float atomics).
+// Measured (profiles/r02_gemm_summary.md): 101 TF on both K = 608 products of the Reddit epoch with
+// the clock warm, MFMA pipe 70 % busy at the ~2.0 GHz the chip holds under this load.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
+
+// Measurement hooks of profiles/experiments/gemm_timeline.hip (which defines them and includes this file); compiled
+// out of the library.
+#ifndef MGGCN_GEMM_STAMP
+#define MGGCN_GEMM_STAMP_DECL
+#define MGGCN_GEMM_STAMP(id)
+#endif
+#ifndef MGGCN_GEMM_QUARTERS        // 1: memory work dealt out between four quarters of a K-step's MFMAs; 0: two halves
+#define MGGCN_GEMM_QUARTERS 0
+#endif
+#ifndef MGGCN_GEMM_SETPRIO         // experiment: 1 = a wave's load / LDS-store sections run at s_setprio 1, its MFMA runs at 0; 2 = the reverse
+#define MGGCN_GEMM_SETPRIO 0
+#endif
 
 namespace {
 
@@ -44,7 +62,6 @@ struct Epilogue {
     size_t ldz = 0;
     float slope = 0.f;
     float *colsum = nullptr;         // also 1^T op(B) -> colsum[N]   (mggcn_gemm_tn_colsum_f32; B stored [K][N])
-    int prio = 0;                    // experiment (MGGCN_GEMM_PRIO): 1 = memory phases at s_setprio 1, 2 = MFMA phase at 1
 };
 
 __device__ __forceinline__ float epilogue_value(const Epilogue &e, float av, float beta, const float *cp, size_t row, size_t col) {
@@ -56,26 +73,22 @@ __device__ __forceinline__ float epilogue_value(const Epilogue &e, float av, flo
     return beta == 0.f ? av : fmaf(beta, *cp, av);
 }
 
-// Loads 4 consecutive elements along the contiguous dimension, zero-filled
-// outside [0, limit).  vec: the whole operand is 16-byte aligned with ld % 4 == 0.
-__device__ __forceinline__ float4 load4_guard(const float *__restrict__ p, long long first,
-                                              long long limit, bool vec) {
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (first + 3 < limit && vec) {
-        r = *reinterpret_cast<const float4 *>(p + first);
-    } else {
-        if (first + 0 < limit) r.x = p[first + 0];
-        if (first + 1 < limit) r.y = p[first + 1];
-        if (first + 2 < limit) r.z = p[first + 2];
-        if (first + 3 < limit) r.w = p[first + 3];
-    }
-    return r;
-}
-
 // One operand's tile staging.  R = rows of the tile in the M (or N) direction.
 // KCONTIG: the stored matrix is [R-dim][K] (K contiguous) -> transpose into Xs[k][r].
 // else   : the stored matrix is [K][R-dim] (R contiguous) -> straight copy.
-template <int R, bool KCONTIG, int NT>
+// VEC    : the operand is 16-byte aligned with ld % 4 == 0 -> one 16-byte load per segment; else four 4-byte loads.
+//
+// The loads are BRANCH-FREE and never leave the matrix:
+//  * rows / columns of the tile beyond the matrix edge (r >= r_limit) read a CLAMPED address and keep what they get:
+//    such a row of the A tile (column of the B tile) only feeds output rows (columns) that the epilogue never stores,
+//    so no mask is needed -- and with VEC a float4 that straddles r_limit still lies inside its row (ld % 4 == 0);
+//  * k beyond k_end reads a clamped address too and is ZEROED afterwards (mask_k_edge) -- only in the one K-step that
+//    contains the edge, a block-uniform branch around register-only code.
+// The first version branched per segment between a vector path, four guarded scalar loads and zero fill, all writing the
+// same registers: the compiler put s_waitcnt vmcnt(0) in front of loads, kept both paths' addresses live across the K
+// loop and spilled at the 128-VGPR budget -- and a scratch reload waits for EVERY outstanding global load
+// (profiles/r02_gemm_summary.md).
+template <int R, bool KCONTIG, int NT, bool VEC>
 struct Stager {
     static constexpr int PAD = KCONTIG ? 1 : 4;
     static constexpr int LD = R + PAD;
@@ -83,22 +96,73 @@ struct Stager {
     static_assert(SEGS >= 1 && R * BK / 4 % NT == 0, "tile does not divide over the threads");
     float4 reg[SEGS];
 
-    __device__ __forceinline__ void load(const float *__restrict__ X, size_t ld, long long r0,
-                                         long long r_limit, long long k0, long long k_limit, bool vec,
-                                         int tid) {
+    // the loop-invariant half of a thread's addresses
+    struct Source {
+        const float *X;
+        size_t ld;
+        long long r_limit;
+        long long r[SEGS];           // KCONTIG: the (clamped) matrix row of segment s; else: its first matrix column
+        __device__ __forceinline__ Source(const float *X_, size_t ld_, long long r0, long long r_limit_, int tid)
+            : X(X_), ld(ld_), r_limit(r_limit_) {
+#pragma unroll
+            for (int s = 0; s < SEGS; s++) {
+                const int f = tid + NT * s;
+                if (KCONTIG) {
+                    const long long row = r0 + f / (BK / 4);
+                    r[s] = row < r_limit ? row : r_limit - 1;
+                } else {
+                    const long long col = r0 + (f % (R / 4)) * 4;
+                    r[s] = (VEC && col >= r_limit) ? 0 : col;
+                }
+            }
+        }
+    };
+
+    __device__ __forceinline__ void load(const Source &src, long long k0, long long k_end, int tid) {
 #pragma unroll
         for (int s = 0; s < SEGS; s++) {
             const int f = tid + NT * s;
             if (KCONTIG) {
-                const int r = f / (BK / 4), kq = f % (BK / 4);
-                const long long row = r0 + r;
-                reg[s] = row < r_limit ? load4_guard(X + (size_t)row * ld, k0 + kq * 4, k_limit, vec)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                const long long k = k0 + (f % (BK / 4)) * 4;
+                const float *row = src.X + (size_t)src.r[s] * src.ld;
+                if (VEC) {
+                    reg[s] = *reinterpret_cast<const float4 *>(row + (k < k_end ? k : 0));
+                } else {
+                    const long long last = k_end - 1;
+                    reg[s].x = row[k + 0 < k_end ? k + 0 : last];
+                    reg[s].y = row[k + 1 < k_end ? k + 1 : last];
+                    reg[s].z = row[k + 2 < k_end ? k + 2 : last];
+                    reg[s].w = row[k + 3 < k_end ? k + 3 : last];
+                }
             } else {
-                const int k = f / (R / 4), q = f % (R / 4);
-                const long long kk = k0 + k;
-                reg[s] = kk < k_limit ? load4_guard(X + (size_t)kk * ld, r0 + q * 4, r_limit, vec)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                const long long k = k0 + f / (R / 4);
+                const float *row = src.X + (size_t)(k < k_end ? k : k_end - 1) * src.ld;
+                if (VEC) {
+                    reg[s] = *reinterpret_cast<const float4 *>(row + src.r[s]);
+                } else {
+                    const long long last = src.r_limit - 1, c = src.r[s];
+                    reg[s].x = row[c + 0 < src.r_limit ? c + 0 : last];
+                    reg[s].y = row[c + 1 < src.r_limit ? c + 1 : last];
+                    reg[s].z = row[c + 2 < src.r_limit ? c + 2 : last];
+                    reg[s].w = row[c + 3 < src.r_limit ? c + 3 : last];
+                }
+            }
+        }
+    }
+
+    // zero what load() fetched for k >= k_end (call when k0 + BK > k_end)
+    __device__ __forceinline__ void mask_k_edge(long long k0, long long k_end, int tid) {
+#pragma unroll
+        for (int s = 0; s < SEGS; s++) {
+            const int f = tid + NT * s;
+            if (KCONTIG) {
+                const long long k = k0 + (f % (BK / 4)) * 4;
+                reg[s].x = k + 0 < k_end ? reg[s].x : 0.f;
+                reg[s].y = k + 1 < k_end ? reg[s].y : 0.f;
+                reg[s].z = k + 2 < k_end ? reg[s].z : 0.f;
+                reg[s].w = k + 3 < k_end ? reg[s].w : 0.f;
+            } else {
+                if (k0 + f / (R / 4) >= k_end) reg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
@@ -121,31 +185,33 @@ struct Stager {
     }
 };
 
-// NT = 256: 4 waves, each 64x64 (BN = 128) or 32x64 (BN = 64) of the tile -- 64 / 32 accumulator registers, ~170 VGPRs,
-//           two workgroups = 2 waves per SIMD.
-// NT = 512: 8 waves, each 32x64 (BN = 128) or 32x32 (BN = 64) -- half the accumulators per wave, ~90 VGPRs, two
-//           workgroups = 4 waves per SIMD: the matrix pipe of a SIMD keeps running while some of its waves sit at
-//           the workgroup barrier or wait for their LDS stores (r01 counters on [n x 608].[608 x 128]: MFMA pipe 55 %
-//           busy, waves parked on s_waitcnt / s_barrier 39 % of their cycles with two waves per SIMD).
-// The K loop is double-buffered in LDS: tile k+1 is written to the other buffer after the MFMAs of tile k, ONE
-// barrier per K-step (the single-buffer loop needed two and serialised store -> compute).
-template <bool A_KCONTIG, bool B_KCONTIG, int BN, int NT>
-__global__ __launch_bounds__(NT) void gemm_mfma_kernel(
+// NT = 512 threads: 8 waves, each 32x64 (BN = 128) or 32x32 (BN = 64), <= 128 VGPRs, two workgroups = 4 waves per
+// SIMD: the matrix pipe of a SIMD keeps running while some of its waves sit at the workgroup barrier or in their
+// load / LDS-store sections.  (The 256-thread layout of round 1 -- 4 waves of 64x64, ~170 VGPRs, 2 waves per SIMD --
+// measured 1.83 ms for the epoch's shapes against 1.54: profiles/experiments/gemm_shapes_r02_threads{256,512}.log.)
+// The K loop is double-buffered in LDS with ONE barrier per K-step.
+template <bool A_KCONTIG, bool B_KCONTIG, int BN, int NT, bool VEC>
+__global__ __launch_bounds__(NT, 4) void gemm_mfma_kernel(   // 4 waves per SIMD: <= 128 VGPRs
     uint32_t M, uint32_t N, uint32_t K, float alpha, const float *__restrict__ A, size_t lda,
     const float *__restrict__ B, size_t ldb, float beta, float *__restrict__ C, size_t ldc,
-    float *__restrict__ slab, uint32_t k_chunk, bool a_vec, bool b_vec, const Epilogue epi) {
+    float *__restrict__ slab, uint32_t k_chunk, const Epilogue epi) {
+    // VEC: BOTH operands are 16-byte aligned with a leading dimension that is a multiple of 4 (every GEMM of the hidden
+    // layers).  A template parameter, not a run-time flag: with the element-wise path compiled into the same kernel its
+    // 4 x the addresses stayed live across the K loop and the kernel spilled at its 128-VGPR budget.
     constexpr int NW = NT / 64;
     constexpr int WN = (BN == 128 || NW == 8) ? 2 : 1;   // waves along N
     constexpr int WM = NW / WN;                     // waves along M
     constexpr int MI = BM / WM / 32;                // MFMA blocks per wave along M
     constexpr int NI = BN / WN / 32;                // along N
     static_assert(MI >= 1 && NI >= 1, "wave tile smaller than one MFMA block");
-    using StA = Stager<BM, A_KCONTIG, NT>;
-    using StB = Stager<BN, B_KCONTIG, NT>;
+    using StA = Stager<BM, A_KCONTIG, NT, VEC>;
+    using StB = Stager<BN, B_KCONTIG, NT, VEC>;
     __shared__ __attribute__((aligned(16))) float As[2][BK * StA::LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * StB::LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    MGGCN_GEMM_STAMP_DECL;
+    MGGCN_GEMM_STAMP(0);
     const int wm = wid / WN, wn = wid % WN;
     const long long m0 = (long long)blockIdx.x * BM, n0 = (long long)blockIdx.y * BN;
     const long long k_begin = (long long)blockIdx.z * k_chunk;
@@ -159,66 +225,139 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    StA sa;
-    StB sb;
+    // Two register sets: while the MFMAs of tile t run, the loads of tile t+2 are in flight and tile t+1 (loaded during
+    // tile t-1, landed by now) is written to the other LDS buffer IN THE MIDDLE of the MFMA sequence -- the matrix pipe
+    // keeps executing the queued MFMAs while the wave issues its ds_writes.  (One set, stores after the last MFMA: every
+    // wave of the workgroup sat in the store / barrier phase at the same time and the pipe idled -- one workgroup alone
+    // on a CU reached 61 TF, two 75: profiles/r02_gemm_summary.md.)
+    StA sa[2];
+    StB sb[2];
     // column sums of B (G_b = 1^T G riding on G_W = X^T G): the workgroups of the FIRST M-tile add up the B tiles
     // they stage anyway -- thread tid always holds columns (tid % (BN/4))*4 .. +3 of its k rows
     const bool do_colsum = !B_KCONTIG && epi.colsum != nullptr && blockIdx.x == 0;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto add_colsum = [&]() {
+    auto add_colsum = [&](const StB &t) {
         if constexpr (!B_KCONTIG) {
             if (do_colsum) {
 #pragma unroll
                 for (int q = 0; q < StB::SEGS; q++) {
-                    csum.x += sb.reg[q].x; csum.y += sb.reg[q].y; csum.z += sb.reg[q].z; csum.w += sb.reg[q].w;
+                    csum.x += t.reg[q].x; csum.y += t.reg[q].y; csum.z += t.reg[q].z; csum.w += t.reg[q].w;
                 }
             }
         }
     };
-    if (k_begin < k_end) {
-        sa.load(A, lda, m0, M, k_begin, k_end, a_vec, tid);
-        sb.load(B, ldb, n0, N, k_begin, k_end, b_vec, tid);
-        add_colsum();
-        sa.store(As[0], tid);
-        sb.store(Bs[0], tid);
-    }
-    __syncthreads();
     const int l31 = lane & 31, lhi = lane >> 5;
-    int cur = 0;
-    for (long long k0 = k_begin; k0 < k_end; k0 += BK, cur ^= 1) {
-        const bool more = k0 + BK < k_end;
-        if (epi.prio == 1) __builtin_amdgcn_s_setprio(1);
-        if (more) {                      // global loads of the next K-step fly under the MFMAs
-            sa.load(A, lda, m0, M, k0 + BK, k_end, a_vec, tid);
-            sb.load(B, ldb, n0, N, k0 + BK, k_end, b_vec, tid);
+    const typename StA::Source src_a(A, lda, m0, M, tid);
+    const typename StB::Source src_b(B, ldb, n0, N, tid);
+    auto load_a = [&](StA &t, long long k0) { t.load(src_a, k0, k_end, tid); };
+    auto load_b = [&](StB &t, long long k0) { t.load(src_b, k0, k_end, tid); };
+    // tile k0 is about to go to LDS: zero its k >= k_end part (block-uniform, at most once per workgroup)
+    auto finish = [&](StA &ta, StB &tb, long long k0) {
+        if (k0 + BK > k_end) {
+            ta.mask_k_edge(k0, k_end, tid);
+            tb.mask_k_edge(k0, k_end, tid);
         }
-        if (epi.prio == 1) __builtin_amdgcn_s_setprio(0);
-        if (epi.prio == 2) __builtin_amdgcn_s_setprio(1);
-        const float *as = As[cur], *bs = Bs[cur];
+    };
+    // operands of k-pair kk+1 are read while the MFMAs of kk issue (two register sets, spelled out: left to itself the
+    // compiler re-used one set and waited out the LDS latency in front of every MFMA pair)
+    auto read_ab = [&](const float *as, const float *bs, int kk, float (&a)[MI], float (&b)[NI]) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; kk++) {
-            float a[MI], b[NI];
+        for (int i = 0; i < MI; i++) a[i] = as[(kk * 2 + lhi) * StA::LD + wm * (BM / WM) + i * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < MI; i++)
-                a[i] = as[(kk * 2 + lhi) * StA::LD + wm * (BM / WM) + i * 32 + l31];
+        for (int j = 0; j < NI; j++) b[j] = bs[(kk * 2 + lhi) * StB::LD + wn * (BN / WN) + j * 32 + l31];
+    };
+    auto mfma_range = [&](const float *as, const float *bs, auto kk_lo, auto kk_hi) {
+        constexpr int LO = decltype(kk_lo)::value, HI = decltype(kk_hi)::value;
+        float a[2][MI], b[2][NI];
+        read_ab(as, bs, LO, a[0], b[0]);
 #pragma unroll
-            for (int j = 0; j < NI; j++)
-                b[j] = bs[(kk * 2 + lhi) * StB::LD + wn * (BN / WN) + j * 32 + l31];
+        for (int kk = LO; kk < HI; kk++) {
+            const int c = (kk - LO) & 1;
+            if (kk + 1 < HI) read_ab(as, bs, kk + 1, a[c ^ 1], b[c ^ 1]);
 #pragma unroll
             for (int i = 0; i < MI; i++)
 #pragma unroll
                 for (int j = 0; j < NI; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
         }
-        if (epi.prio == 2) __builtin_amdgcn_s_setprio(0);
-        if (epi.prio == 1) __builtin_amdgcn_s_setprio(1);
-        if (more) {                      // the other buffer: nobody reads it until the barrier below
-            add_colsum();
-            sa.store(As[cur ^ 1], tid);
-            sb.store(Bs[cur ^ 1], tid);
+    };
+    using q0 = std::integral_constant<int, 0>;
+    using q1 = std::integral_constant<int, BK / 8>;
+    using q2 = std::integral_constant<int, BK / 4>;
+    using q3 = std::integral_constant<int, 3 * BK / 8>;
+    using q4 = std::integral_constant<int, BK / 2>;
+    // one K-step: tile (k0) is in LDS buffer CUR; set NXT holds tile k0 + BK (in flight or landed); set CUR is free.
+    // The memory work of the step is dealt out between the four quarters of the MFMA sequence, so a wave never leaves
+    // the matrix pipe without queued work for long: it issues a few loads / LDS stores while its last MFMAs execute.
+    auto step = [&](long long k0, auto cur_c) {
+        constexpr int CUR = decltype(cur_c)::value, NXT = CUR ^ 1;
+        const bool more2 = k0 + 2 * BK < k_end, more1 = k0 + BK < k_end;
+        MGGCN_GEMM_STAMP(1);
+#if MGGCN_GEMM_QUARTERS
+        if (more2) load_a(sa[CUR], k0 + 2 * BK);       // tile t+2 -> the register set tile t came from
+        MGGCN_GEMM_STAMP(2);
+        mfma_range(As[CUR], Bs[CUR], q0{}, q1{});
+        if (more2) load_b(sb[CUR], k0 + 2 * BK);
+        mfma_range(As[CUR], Bs[CUR], q1{}, q2{});
+        MGGCN_GEMM_STAMP(3);
+        if (more1) {                                   // tile t+1 -> the other LDS buffer (nobody reads it until the barrier below)
+            finish(sa[NXT], sb[NXT], k0 + BK);
+            sa[NXT].store(As[NXT], tid);
         }
-        if (epi.prio == 1) __builtin_amdgcn_s_setprio(0);
+        MGGCN_GEMM_STAMP(4);
+        mfma_range(As[CUR], Bs[CUR], q2{}, q3{});
+        if (more1) {
+            add_colsum(sb[NXT]);
+            sb[NXT].store(Bs[NXT], tid);
+        }
+        mfma_range(As[CUR], Bs[CUR], q3{}, q4{});
+#else
+        if (MGGCN_GEMM_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (MGGCN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if (more2) {
+            load_a(sa[CUR], k0 + 2 * BK);
+            load_b(sb[CUR], k0 + 2 * BK);
+        }
+        MGGCN_GEMM_STAMP(2);
+        if (MGGCN_GEMM_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (MGGCN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(1);
+        mfma_range(As[CUR], Bs[CUR], q0{}, q2{});
+        MGGCN_GEMM_STAMP(3);
+        if (MGGCN_GEMM_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (MGGCN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(0);
+        if (more1) {
+            finish(sa[NXT], sb[NXT], k0 + BK);
+            add_colsum(sb[NXT]);
+            sa[NXT].store(As[NXT], tid);
+            sb[NXT].store(Bs[NXT], tid);
+        }
+        MGGCN_GEMM_STAMP(4);
+        if (MGGCN_GEMM_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (MGGCN_GEMM_SETPRIO == 2) __builtin_amdgcn_s_setprio(1);
+        mfma_range(As[CUR], Bs[CUR], q2{}, q4{});
+        if (MGGCN_GEMM_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
+#endif
+        MGGCN_GEMM_STAMP(5);
         __syncthreads();
+        MGGCN_GEMM_STAMP(6);
+    };
+    if (k_begin < k_end) {
+        load_a(sa[0], k_begin);
+        load_b(sb[0], k_begin);
+        if (k_begin + BK < k_end) {
+            load_a(sa[1], k_begin + BK);
+            load_b(sb[1], k_begin + BK);
+        }
+        finish(sa[0], sb[0], k_begin);
+        add_colsum(sb[0]);
+        sa[0].store(As[0], tid);
+        sb[0].store(Bs[0], tid);
+    }
+    __syncthreads();
+    MGGCN_GEMM_STAMP(9);
+    for (long long k0 = k_begin; k0 < k_end; k0 += 2 * BK) {
+        step(k0, std::integral_constant<int, 0>{});
+        if (k0 + BK < k_end) step(k0 + BK, std::integral_constant<int, 1>{});
     }
     if constexpr (!B_KCONTIG) {
         if (do_colsum) {                 // block-uniform.  Fold the NT / (BN/4) threads of a column group in order.
@@ -227,6 +366,7 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(
             __syncthreads();
             if (tid < BN / 4) {
                 float4 t = red[tid];
+#pragma unroll 4                          // fully unrolled (32 float4 live at BN = 64) this fold alone spilled to scratch
                 for (int g = 1; g < NT / (BN / 4); g++) {
                     const float4 o = red[tid + g * (BN / 4)];
                     t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
@@ -243,27 +383,53 @@ __global__ __launch_bounds__(NT) void gemm_mfma_kernel(
         }
     }
 
-    // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    MGGCN_GEMM_STAMP(7);
+    // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // One block-uniform choice of what happens to the value, then per 32x32 block: the 16 auxiliary reads (old C for
+    // beta != 0, Z for the leaky-ReLU mask) are all issued before the first is consumed, and an element's address is
+    // the lane's block corner + a wave-uniform (r-dependent) offset.  (First version: epilogue_value() per element --
+    // a 64-bit multiply, three branches and, with a mask or beta, one full memory round trip per element, 32 in a row.)
     const bool to_slab = gridDim.z > 1;
+    float *out = to_slab ? slab + (size_t)blockIdx.z * (M + (epi.colsum ? 1 : 0)) * N : C;
+    const size_t ldo = to_slab ? (size_t)N : ldc;
+    enum { kPlain, kBias, kMask, kBeta };
+    const int kind = to_slab ? kPlain : epi.bias ? kBias : epi.mask ? kMask : beta != 0.f ? kBeta : kPlain;
+    const float scale = to_slab ? 1.f : alpha;
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < NI; j++) {
             const long long col = n0 + wn * (BN / WN) + j * 32 + l31;
+            const long long row0 = m0 + wm * (BM / WM) + i * 32 + 4 * lhi;
+            if (col >= N) continue;
+            float *corner = out + (size_t)row0 * ldo + col;
+            const long long rows_left = (long long)M - row0;          // element r is in range iff its row offset < rows_left
+            float aux[16];
+            if (kind == kMask || kind == kBeta) {
+                const float *src = kind == kMask ? epi.mask + (size_t)row0 * epi.ldz + col : corner;
+                const size_t lds = kind == kMask ? epi.ldz : ldo;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const long long row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (row < M && col < N) {
-                    const float v = acc[i][j][r];
-                    if (to_slab) {
-                        slab[((size_t)blockIdx.z * (M + (epi.colsum ? 1 : 0)) + row) * N + col] = v;
-                    } else {
-                        float *cp = C + (size_t)row * ldc + col;
-                        *cp = epilogue_value(epi, alpha * v, beta, cp, (size_t)row, (size_t)col);
-                    }
+                for (int r = 0; r < 16; r++) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    aux[r] = ro < rows_left ? src[(size_t)ro * lds] : 0.f;
                 }
             }
+            const float bias = kind == kBias ? epi.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                const float av = scale * acc[i][j][r];
+                float v = av;
+                // bias: the row vector the reference broadcasts into C before its beta = 1 sgemm (src/gcn.hpp:116-123),
+                // same single rounding as fmaf(1, bias, alpha*v); mask: leaky_relu_backward of the consumer
+                // (src/cuda_utils.cu:33-38) on the value a beta = 0 GEMM would store
+                if (kind == kBias) v = fmaf(1.f, bias, av);
+                else if (kind == kMask) v = aux[r] > 0.f ? av : epi.slope * av;
+                else if (kind == kBeta) v = fmaf(beta, aux[r], av);
+                if (ro < rows_left) corner[(size_t)ro * ldo] = v;
+            }
         }
+    MGGCN_GEMM_STAMP(8);
 }
 
 // C = alpha * sum_z slab[z] + beta * C.  256 threads = 32 outputs x 8 split-groups: group g adds
@@ -362,16 +528,6 @@ struct Split {
 };
 
 constexpr uint32_t kThinRows = 4;
-
-// threads per workgroup of the MFMA kernel (see gemm_mfma_kernel); MGGCN_GEMM_THREADS = 256 | 512 for experiments
-inline int gemm_threads() {
-    static const int nt = [] {
-        const char *e = std::getenv("MGGCN_GEMM_THREADS");
-        const int v = e ? std::atoi(e) : 512;
-        return v == 256 ? 256 : 512;
-    }();
-    return nt;
-}
 
 inline bool use_thin(int trans_a, int trans_b, uint32_t M, uint32_t K) {
     return !trans_a && !trans_b && M <= kThinRows && K >= 4096;
@@ -484,8 +640,6 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
                    void *workspace, size_t workspace_bytes, const Epilogue &epi_in) {
     if (!M || !N) return;
     Epilogue epi = epi_in;
-    static const int prio_env = [] { const char *e = std::getenv("MGGCN_GEMM_PRIO"); return e ? std::atoi(e) : 0; }();
-    epi.prio = prio_env;
     hipStream_t st = as_stream(stream);
     MGGCN_REQUIRE(C != nullptr && ldc >= N, "bad C / ldc");
     if (!K) {
@@ -525,13 +679,14 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
     const int bn = N > 64 ? 128 : 64;
     const dim3 grid((M + BM - 1) / BM, (N + bn - 1) / bn, sp.splits);
 
-    const int nt = gemm_threads();
-    const dim3 blk(nt);
-#define MGGCN_GEMM_LAUNCH(AK, BKC, BNV, NTV)                                                               \
-    hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKC, BNV, NTV>), grid, blk, 0, st, M, N, K, alpha, A, lda, B, ldb, \
-                       beta, C, ldc, slab, sp.k_chunk, a_vec, b_vec, epi)
+    const dim3 blk(512);
+    // experiment knob: extra dynamic LDS per workgroup (bytes) to cap the workgroups resident per CU
+    static const unsigned dyn_lds = [] { const char *e = std::getenv("MGGCN_GEMM_DYN_LDS"); return e ? (unsigned)std::atoi(e) : 0u; }();
+#define MGGCN_GEMM_LAUNCH(AK, BKC, BNV, VECV)                                                             \
+    hipLaunchKernelGGL((gemm_mfma_kernel<AK, BKC, BNV, 512, VECV>), grid, blk, dyn_lds, st, M, N, K, alpha, A, lda, B, \
+                       ldb, beta, C, ldc, slab, sp.k_chunk, epi)
 #define MGGCN_GEMM_LAUNCH_NT(AK, BKC, BNV) \
-    do { if (nt == 512) MGGCN_GEMM_LAUNCH(AK, BKC, BNV, 512); else MGGCN_GEMM_LAUNCH(AK, BKC, BNV, 256); } while (0)
+    do { if (a_vec && b_vec) MGGCN_GEMM_LAUNCH(AK, BKC, BNV, true); else MGGCN_GEMM_LAUNCH(AK, BKC, BNV, false); } while (0)
     if (bn == 128) {
         if (a_kc && b_kc) MGGCN_GEMM_LAUNCH_NT(true, true, 128);
         else if (a_kc) MGGCN_GEMM_LAUNCH_NT(true, false, 128);
