@@ -53,6 +53,12 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ f32x4_t mggcn_buffer_load_v4f32(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.ptr.buffer.load.v4f32");
 
+// cache-policy bits of the pair kernel's row gathers (experiment, profiles/experiments/gather_aux.sh): gfx940+ encoding
+// 1 = sc0, 2 = nt, 16 = sc1
+#ifndef MGGCN_GATHER_AUX
+#define MGGCN_GATHER_AUX 0
+#endif
+
 namespace {
 
 constexpr int kRW = 16;                 // output rows per wave (5 bits available)
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
                     const uint32_t off_a = (cur.pk(2 * u) & kColMask) * row_bytes;
                     const uint32_t off_b = (cur.pk(2 * u + 1) & kColMask) * row_bytes;     // >= off_a
                     const uint32_t voff = lane_off + ((off_b - off_a) & hmask);
-                    b[u] = mggcn_buffer_load_v4f32(rsrc, (int)voff, (int)off_a, 0);
+                    b[u] = mggcn_buffer_load_v4f32(rsrc, (int)voff, (int)off_a, MGGCN_GATHER_AUX);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
