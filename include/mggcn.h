@@ -262,11 +262,16 @@ void mggcn_gather_rows_f32(mggcn_stream_t stream, const float *src, size_t ld_sr
  *   O = softmax(H) row-wise (max-subtracted); P = argmax (first wins);
  *   loss_terms[i] = log O[i, Y[i]];  correct[i] = (Y[i] == P[i]);
  *   H <- (O - onehot(Y)) * grad_scale           (grad_scale = 1 / n_global)
- *   sums[0] += sum_i |loss_terms[i]|, sums[1] += sum_i correct[i]  (caller zeroes sums;
- *   float atomics across workgroups: last-bit order dependence only in the two
- *   reported scalars, never in the gradient). */
+ *   sums[0] += sum_i |loss_terms[i]|, sums[1] += sum_i correct[i]  (the caller zeroes sums;
+ *   workgroup partials are added in a fixed order by a one-workgroup second launch:
+ *   bitwise reproducible, no atomics). */
 void mggcn_softmax_xent_fused_f32(mggcn_stream_t stream, float *H, const int32_t *Y, size_t n_rows,
                                   size_t m, float grad_scale, float *sums_device);
+/* The same pass out of place: reads `logits`, writes the gradient to G (G == logits is the call above).  With
+ * copy = true the reference copies the logits before its in-place chain (src/gcn.hpp:653-656, :787): here the copy
+ * is the pass itself. */
+void mggcn_softmax_xent_fused_from_f32(mggcn_stream_t stream, const float *logits, float *G, const int32_t *Y,
+                                       size_t n_rows, size_t m, float grad_scale, float *sums_device);
 /* One launch for linear::adam_update on a parameter tensor (src/gcn.hpp:146-172):
  *   g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
  *   p -= (lr/c1) * m / (sqrt(v/c2) + eps)      (g is updated in place like the reference) */

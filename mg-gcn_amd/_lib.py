@@ -86,6 +86,7 @@ PROTOTYPES = {
     "mggcn_abssum_f32": (None, [vp, vp, c_size_t, vp]),
     "mggcn_gather_rows_f32": (None, [vp, vp, c_size_t, vp, c_size_t, c_uint32, vp, c_size_t]),
     "mggcn_softmax_xent_fused_f32": (None, [vp, vp, vp, c_size_t, c_size_t, c_float, vp]),
+    "mggcn_softmax_xent_fused_from_f32": (None, [vp, vp, vp, vp, c_size_t, c_size_t, c_float, vp]),
     "mggcn_adam_fused_f32": (None, [vp, vp, vp, vp, vp, c_float, c_float, c_float, c_float, c_float,
                                     c_float, c_float, c_size_t]),
     "mggcn_adam_multi_blocks": (c_uint32, [c_uint64]),

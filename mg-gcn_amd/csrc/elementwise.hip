@@ -239,6 +239,8 @@ __global__ __launch_bounds__(256) void adam_final_kernel(float *__restrict__ par
 
 // ---- |x| sum: fixed-order two-level reduction (reproducible) ---------------
 constexpr unsigned kAsumBlocks = 1024;
+constexpr unsigned kXentBlocks = kNumCU * 8;               // grid cap of the fused loss (stream_grid)
+constexpr unsigned kScratchFloats = 2 * kXentBlocks;        // abssum partials / the fused loss's (loss, correct) pairs
 
 __global__ __launch_bounds__(256) void abssum_partial_kernel(const float *__restrict__ A, size_t size,
                                                              float *__restrict__ partial) {
@@ -274,7 +276,7 @@ float *abssum_scratch(hipStream_t st) {
     MGGCN_CHECK_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
     float *&p = scratch[{dev, st}];
-    if (!p) MGGCN_CHECK_HIP(hipMalloc(&p, kAsumBlocks * sizeof(float)));
+    if (!p) MGGCN_CHECK_HIP(hipMalloc(&p, kScratchFloats * sizeof(float)));
     return p;
 }
 
@@ -285,11 +287,12 @@ constexpr int kXentMaxPerLane = 16;  // m <= 1024
 // R rows are in flight per wave (their loads issued together): with one row at a time every row is a dependent
 // HBM round trip -- load, six shuffle steps, store -- and the pass was latency-bound at 0.7 TB/s (r01: 110 us for
 // the 76 MB of the [233 k x 41] logits); four rows in flight hide it.
+// (src and dst may be the same matrix: a row is read whole before any of it is written)
 template <int K, int R>
-__global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restrict__ H,
+__global__ __launch_bounds__(256) void softmax_xent_fused_kernel(const float *src, float *dst,
                                                                  const int32_t *__restrict__ Y,
                                                                  size_t n_rows, size_t m, float grad_scale,
-                                                                 float *__restrict__ sums) {
+                                                                 float *__restrict__ partials) {
     __shared__ float s_loss[4], s_acc[4];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t wstride = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restri
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const size_t c = (size_t)lane + 64u * k;
-                x[q][k] = (live && c < m) ? H[r * m + c] : -INFINITY;
+                x[q][k] = (live && c < m) ? src[r * m + c] : -INFINITY;
             }
         }
 #pragma unroll
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restri
                 if (c < m) {
                     const float o = x[q][k] / sum;
                     const bool hit = (int32_t)c == y[q];
-                    H[r * m + c] = (hit ? o - 1.f : o) * grad_scale;
+                    dst[r * m + c] = (hit ? o - 1.f : o) * grad_scale;
                     x[q][k] = o;
                 }
             }
@@ -358,9 +361,115 @@ __global__ __launch_bounds__(256) void softmax_xent_fused_kernel(float *__restri
     }
     if (lane == 0) { s_loss[wid] = loss_acc; s_acc[wid] = corr_acc; }
     __syncthreads();
+    if (threadIdx.x == 0) {              // one (loss, correct) pair per workgroup, summed by xent_final_kernel
+        partials[2 * blockIdx.x + 0] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        partials[2 * blockIdx.x + 1] = (s_acc[0] + s_acc[1]) + (s_acc[2] + s_acc[3]);
+    }
+}
+
+// m <= 64 (the logits layer: 41 classes, 48 at P = 8): one row per 16-LANE GROUP, KE = ceil(m / 16) logits per lane, so a
+// wave works on four rows at once and every reduction is four DPP rotations inside the 16-lane row (row_ror 8, 4, 2, 1:
+// a butterfly -- both lanes of a pair add the same two numbers, so all 16 lanes end with the same bits), no v_readlane,
+// no cross-row step.  The wave-per-row form above keeps 41 of 64 lanes busy and spends a full wave reduction per row:
+// 105 us for the [233 k x 41] logits (0.7 TB/s); this one issues a quarter of the instructions per row.
+template <typename T, typename Op>
+__device__ __forceinline__ T row16_reduce(T v, Op op) {
+    auto ror = [](T x, auto ctrl) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    v = op(v, ror(v, std::integral_constant<int, 0x128>{}));    // row_ror:8
+    v = op(v, ror(v, std::integral_constant<int, 0x124>{}));    // row_ror:4
+    v = op(v, ror(v, std::integral_constant<int, 0x122>{}));    // row_ror:2
+    v = op(v, ror(v, std::integral_constant<int, 0x121>{}));    // row_ror:1
+    return v;
+}
+
+template <int KE, int R>
+__global__ __launch_bounds__(256) void softmax_xent_rows16_kernel(const float *src, float *dst,
+                                                                  const int32_t *__restrict__ Y, size_t n_rows,
+                                                                  uint32_t m, float grad_scale, float *__restrict__ partials) {
+    __shared__ float s_loss[4], s_acc[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint32_t sub = lane & 15;
+    const size_t gstride = ((size_t)gridDim.x * blockDim.x) >> 4;           // 16-lane groups in the grid
+    const size_t g0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const size_t w0 = g0 & ~(size_t)3;                                       // first group of this wave
+    float loss_acc = 0.f, corr_acc = 0.f;
+    for (size_t base = 0; w0 + base < n_rows; base += gstride * R) {         // wave-uniform trip count
+        float x[R][KE];
+        int32_t y[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {                                        // all loads first
+            const size_t r = g0 + base + (size_t)q * gstride;
+            const bool live = r < n_rows;
+            y[q] = live ? Y[r] : 0;
+#pragma unroll
+            for (int k = 0; k < KE; k++) {
+                const uint32_t c = sub + 16u * k;
+                x[q][k] = (live && c < m) ? src[r * m + c] : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const size_t r = g0 + base + (size_t)q * gstride;
+            const bool live = r < n_rows;
+            float mx = x[q][0];
+#pragma unroll
+            for (int k = 1; k < KE; k++) mx = fmaxf(mx, x[q][k]);
+            mx = row16_reduce(mx, [](float a, float b) { return fmaxf(a, b); });
+            // FIRST column holding the maximum (strict `<` of the reference, cuda_utils.cu:126); none (all -inf / NaN) -> 0
+            uint32_t idx = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = KE - 1; k >= 0; k--)
+                if (x[q][k] == mx && sub + 16u * k < m) idx = sub + 16u * k;
+            idx = row16_reduce(idx, [](uint32_t a, uint32_t b) { return a < b ? a : b; });
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KE; k++) {
+                x[q][k] = sub + 16u * k < m ? expf(x[q][k] - mx) : 0.f;
+                sum += x[q][k];
+            }
+            sum = row16_reduce(sum, [](float a, float b) { return a + b; });
+            float py = 0.f;                                                  // p_y: exactly one lane / slot holds column y
+#pragma unroll
+            for (int k = 0; k < KE; k++) {
+                const uint32_t c = sub + 16u * k;
+                const float o = x[q][k] / sum;
+                const bool hit = (int32_t)c == y[q];
+                if (live && c < m) dst[r * m + c] = (hit ? o - 1.f : o) * grad_scale;
+                if (hit && c < m) py = o;
+            }
+            py = row16_reduce(py, [](float a, float b) { return a + b; });   // the others are exact zeros
+            if (live && sub == 0) {
+                loss_acc += fabsf(logf(py));
+                corr_acc += ((idx == 0xFFFFFFFFu ? 0 : (int32_t)idx) == y[q]) ? 1.f : 0.f;
+            }
+        }
+    }
+    loss_acc = wave_sum_dpp(loss_acc);
+    corr_acc = wave_sum_dpp(corr_acc);
+    if (lane == 0) { s_loss[wid] = loss_acc; s_acc[wid] = corr_acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {              // one (loss, correct) pair per workgroup, summed by xent_final_kernel
+        partials[2 * blockIdx.x + 0] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+        partials[2 * blockIdx.x + 1] = (s_acc[0] + s_acc[1]) + (s_acc[2] + s_acc[3]);
+    }
+}
+
+// sums[0] += sum of the workgroups' loss terms, sums[1] += their correct counts, in a fixed order.  (First version: two
+// float atomics per workgroup on the same two addresses -- 4096 device-scope read-modify-writes in a row were most of the
+// pass: 61 us for any m <= 64; and the two scalars depended on arrival order in their last bits.)
+__global__ __launch_bounds__(256) void xent_final_kernel(const float *__restrict__ partials, unsigned n_blocks,
+                                                         float *__restrict__ sums) {
+    __shared__ float w[2][4];
+    float l = 0.f, a = 0.f;
+    for (unsigned i = threadIdx.x; i < n_blocks; i += 256) { l += partials[2 * i]; a += partials[2 * i + 1]; }
+    l = wave_sum(l); a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) { w[0][threadIdx.x >> 6] = l; w[1][threadIdx.x >> 6] = a; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&sums[0], (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]));
-        atomicAdd(&sums[1], (s_acc[0] + s_acc[1]) + (s_acc[2] + s_acc[3]));
+        sums[0] += (w[0][0] + w[0][1]) + (w[0][2] + w[0][3]);
+        sums[1] += (w[1][0] + w[1][1]) + (w[1][2] + w[1][3]);
     }
 }
 
@@ -562,24 +671,48 @@ MGGCN_API void mggcn_abssum_f32(mggcn_stream_t stream, const float *A, size_t si
     MGGCN_CHECK_LAUNCH();
 }
 
-MGGCN_API void mggcn_softmax_xent_fused_f32(mggcn_stream_t stream, float *H, const int32_t *Y,
-                                            size_t n_rows, size_t m, float grad_scale, float *sums_device) {
+MGGCN_API void mggcn_softmax_xent_fused_from_f32(mggcn_stream_t stream, const float *logits, float *G, const int32_t *Y,
+                                                 size_t n_rows, size_t m, float grad_scale, float *sums_device) {
     if (!n_rows) return;
     MGGCN_REQUIRE(m > 0 && m <= 64u * kXentMaxPerLane, "fused loss supports 1 <= m <= 1024 classes");
-    // (tried: two workgroups per CU to thin out the two contended scalar atomics at the end of every workgroup --
-    //  105 -> 145 us: the pass wants the occupancy; its cost is the ~30 ds_bpermute wave-reductions per row)
-    const dim3 grid(stream_grid(n_rows * 64)), block(256);
+    MGGCN_REQUIRE(logits != nullptr && G != nullptr && Y != nullptr && sums_device != nullptr, "fused loss: null operand");
     hipStream_t st = as_stream(stream);
+    const dim3 block(256);
+    float *partials = abssum_scratch(st);        // per (device, stream); stream order keeps its users apart
+    if (m <= 64) {                               // one row per 16-lane group
+        const dim3 grid(stream_grid(n_rows * 16));
+#define MGGCN_XENT16(KE)                                                                                   \
+    hipLaunchKernelGGL((softmax_xent_rows16_kernel<KE, 4>), grid, block, 0, st, logits, G, Y, n_rows, (uint32_t)m, \
+                       grad_scale, partials)
+        if (m <= 16) MGGCN_XENT16(1);
+        else if (m <= 32) MGGCN_XENT16(2);
+        else if (m <= 48) MGGCN_XENT16(3);
+        else MGGCN_XENT16(4);
+#undef MGGCN_XENT16
+        MGGCN_CHECK_LAUNCH();
+        hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(256), 0, st, partials, grid.x, sums_device);
+        MGGCN_CHECK_LAUNCH();
+        return;
+    }
+    // (tried on the wave-per-row form: two workgroups per CU to thin out the two contended scalar atomics at the end of
+    //  every workgroup -- 105 -> 145 us: the pass wants the occupancy)
+    const dim3 grid(stream_grid(n_rows * 64));
 #define MGGCN_XENT(K, R)                                                                              \
-    hipLaunchKernelGGL((softmax_xent_fused_kernel<K, R>), grid, block, 0, st, H, Y, n_rows, m, grad_scale, \
-                       sums_device)
-    if (m <= 64) MGGCN_XENT(1, 4);
-    else if (m <= 128) MGGCN_XENT(2, 4);
+    hipLaunchKernelGGL((softmax_xent_fused_kernel<K, R>), grid, block, 0, st, logits, G, Y, n_rows, m, grad_scale, \
+                       partials)
+    if (m <= 128) MGGCN_XENT(2, 4);
     else if (m <= 256) MGGCN_XENT(4, 2);
     else if (m <= 512) MGGCN_XENT(8, 1);
     else MGGCN_XENT(16, 1);
 #undef MGGCN_XENT
     MGGCN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(xent_final_kernel, dim3(1), dim3(256), 0, st, partials, grid.x, sums_device);
+    MGGCN_CHECK_LAUNCH();
+}
+
+MGGCN_API void mggcn_softmax_xent_fused_f32(mggcn_stream_t stream, float *H, const int32_t *Y,
+                                            size_t n_rows, size_t m, float grad_scale, float *sums_device) {
+    mggcn_softmax_xent_fused_from_f32(stream, H, H, Y, n_rows, m, grad_scale, sums_device);
 }
 
 MGGCN_API uint32_t mggcn_adam_multi_blocks(uint64_t size) { return (uint32_t)((size + 1023) / 1024); }

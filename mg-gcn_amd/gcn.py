@@ -321,14 +321,13 @@ class softmax_cross_entropy_loss:
         if self.sums is None:
             self.sums = torch.empty(2, dtype=torch.float32, device=ctx.device)
         if self.fused:
-            if self.copy:
-                if self.G is None:
+            if self.copy:                       # the reference copies, then works in place (gcn.hpp:653-656): here the
+                if self.G is None:              # pass reads the logits and writes the gradient elsewhere
                     self.G = dn_matrix(H.n(), H.m())
-                H.copy_to(ctx, self.G)
             else:
                 self.G = H
             ctx.lib.mggcn_memset_zero(self.sums.data_ptr(), 8, ctx.stream(0))
-            ops.softmax_xent_fused(ctx, self.G, Y, 1.0 / n_global, self.sums)
+            ops.softmax_xent_fused(ctx, H, Y, 1.0 / n_global, self.sums, out=self.G)
         else:
             O = self.softmax_layer(ctx, H)
             if self.P is None:

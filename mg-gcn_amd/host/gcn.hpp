@@ -574,14 +574,13 @@ public:
         ctx.set();
         if (!sums_) sums_ = mggcn::device_malloc<r_t>(2);
         if (fused) {
-            if (copy) {
+            if (copy) {                       // reference: copy, then in place (:653-656); here the pass writes elsewhere
                 if (!G.buffer()) G = dn_matrix<r_t>(H.n(), H.m());
-                H.copy_to(ctx, G);
             } else {
                 G = H;
             }
             mggcn_memset_zero(sums_.get(), 2 * sizeof(r_t), ctx.stream(0));
-            softmax_xent_fused(ctx, G, Y, (r_t)1 / (r_t)n_global, sums_.get());
+            softmax_xent_fused(ctx, H, G, Y, (r_t)1 / (r_t)n_global, sums_.get());
             return;
         }
         auto O = softmax_layer(ctx, H);

@@ -441,6 +441,15 @@ void softmax_xent_fused(const context ctx, const dn_matrix<r_t> H, const dn_matr
     ctx.set();
     mggcn_softmax_xent_fused_f32(ctx.stream(0), H.buffer(), Y.buffer(), H.n(), H.m(), grad_scale, sums_device);
 }
+// out of place: logits H -> gradient G (the loss layer's copy = true without the copy)
+template <typename r_t, typename x_t>
+void softmax_xent_fused(const context ctx, const dn_matrix<r_t> H, const dn_matrix<r_t> G, const dn_matrix<x_t> Y, r_t grad_scale,
+                        r_t *sums_device) {
+    mggcn_require(H.n() == Y.n() && Y.m() == 1, "softmax_xent_fused: labels must be n x 1");
+    mggcn_require(G.n() == H.n() && G.m() == H.m(), "softmax_xent_fused: gradient matrix must have the logits' shape");
+    ctx.set();
+    mggcn_softmax_xent_fused_from_f32(ctx.stream(0), H.buffer(), G.buffer(), Y.buffer(), H.n(), H.m(), grad_scale, sums_device);
+}
 
 // dist_context forms: per-GPU loops, as in the reference's "template<dn_t>" overloads
 #define MGGCN_DIST_LOOP(call) for (std::size_t i = 0; i < ctx.size(); i++) { call; }

@@ -246,10 +246,16 @@ def abssum(ctx: context, A: dn_matrix, result_device) -> None:
 
 
 # ---- fused tail ------------------------------------------------
-def softmax_xent_fused(ctx: context, H: dn_matrix, Y: dn_matrix, grad_scale: float, sums_device) -> None:
+def softmax_xent_fused(ctx: context, H: dn_matrix, Y: dn_matrix, grad_scale: float, sums_device,
+                       out: Optional[dn_matrix] = None) -> None:
+    """softmax + argmax + log-prob + gradient in one pass; in place on H, or H -> out (the loss layer's copy = True:
+    the pass is the copy)"""
     _req(H.n() == Y.n() and Y.m() == 1, "labels must be n x 1")
-    ctx.lib.mggcn_softmax_xent_fused_f32(ctx.stream(0), H.buffer(), Y.buffer(), H.n(), H.m(), grad_scale,
-                                         sums_device.data_ptr())
+    if out is None:
+        out = H
+    _req(out.n() == H.n() and out.m() == H.m(), "fused loss: gradient matrix must have the logits' shape")
+    ctx.lib.mggcn_softmax_xent_fused_from_f32(ctx.stream(0), H.buffer(), out.buffer(), Y.buffer(), H.n(), H.m(),
+                                              grad_scale, sums_device.data_ptr())
 
 
 def adam_fused(ctx: context, param: dn_matrix, grad: dn_matrix, m: dn_matrix, v: dn_matrix, lr: float,
