@@ -886,7 +886,7 @@ class dist_row_softmax_cross_entropy_loss:
     all-reduce does it."""
 
     def __init__(self, name: str, copy: bool = True, fused: bool = False):
-        self.inner = softmax_cross_entropy_loss(name, copy, fused)
+        self.inner = softmax_cross_entropy_loss(name, copy, fused, host_sums=False)     # all-reduced as a device tensor
 
     def __call__(self, dctx: dist_context, H: dist_row_dn_matrix, Y: dist_row_dn_matrix, sync: bool = True):
         self.inner(dctx.ctx, H.local, Y.local, n_global=Y.n(), sync=False)

@@ -21,7 +21,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import ops
-from .matrix import context, csr_matrix, dn_matrix
+from .matrix import context, csr_matrix, dn_matrix, host_scalars
 
 MGGCN_SPMM_LEAKY_RELU = 1
 _SQRT_1_3 = float(np.sqrt(np.float32(1.0) / np.float32(3)))     # b.init(std::sqrt((r_t)1.0 / 3)), gcn.hpp:109
@@ -304,10 +304,12 @@ class softmax_cross_entropy_loss:
     """reference src/gcn.hpp:769-823.  Returns (loss, acc) = (sum|log p_y|, #correct) / n
     after a device sync, exactly where the reference blocks (:816-817)."""
 
-    def __init__(self, name: str, copy: bool = True, fused: bool = False):
+    def __init__(self, name: str, copy: bool = True, fused: bool = False, host_sums: bool = True):
+        """host_sums: keep the two reported scalars in mapped pinned host memory (read without a device-to-host copy);
+        False = a device tensor (the distributed wrapper all-reduces it over RCCL)"""
         self.name = name
         self.softmax_layer = softmax(copy)
-        self.copy, self.fused = copy, fused
+        self.copy, self.fused, self.host_sums = copy, fused, host_sums
         self.G = self.L = self.P = self.T = None
         self.sums = None
 
@@ -319,7 +321,7 @@ class softmax_cross_entropy_loss:
             n_global = Y.n()
         ctx.record(n + "0_loss-layer", 0)
         if self.sums is None:
-            self.sums = torch.empty(2, dtype=torch.float32, device=ctx.device)
+            self.sums = host_scalars(2) if self.host_sums else torch.empty(2, dtype=torch.float32, device=ctx.device)
         if self.fused:
             if self.copy:                       # the reference copies, then works in place (gcn.hpp:653-656): here the
                 if self.G is None:              # pass reads the logits and writes the gradient elsewhere
@@ -355,7 +357,7 @@ class softmax_cross_entropy_loss:
     def read(self, ctx: context):
         """(loss, acc) of the last call; the caller has synchronised (train_step reads after the
         whole epoch is done instead of blocking between forward and backward)."""
-        s = self.sums.cpu().numpy()
+        s = self.sums.numpy() if self.host_sums else self.sums.cpu().numpy()
         return float(np.float32(s[0]) / np.float32(self._n)), float(np.float32(s[1]) / np.float32(self._n))
 
     def backward(self) -> dn_matrix:

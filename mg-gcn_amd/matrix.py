@@ -103,6 +103,51 @@ class context:
         return self._workspace
 
 
+class host_scalars:
+    """A few float32 scalars in MAPPED PINNED host memory (mggcn_malloc_host): kernels write them through the same
+    address, the host reads them after a synchronisation without a device-to-host copy (the epoch's loss / accuracy:
+    a `tensor.cpu()` there cost a blit kernel and ~70 us of idle GPU per epoch).  Quacks like the slice of a torch
+    tensor where the ops layer needs it: data_ptr(), [a:b]."""
+
+    def __init__(self, n: int, _base=None, _offset: int = 0):
+        import ctypes
+        self._n, self._offset = n, _offset
+        if _base is None:
+            lib = _lib.load()
+            ptr = lib.mggcn_malloc_host(4 * n)
+            if not ptr:
+                raise MemoryError("mggcn_malloc_host")
+            self._owner = self
+            self._ptr, self._lib = ptr, lib
+            self._view = np.ctypeslib.as_array((ctypes.c_float * n).from_address(ptr))
+            self._view[:] = 0.0
+        else:
+            self._owner = _base
+            self._ptr, self._lib = _base._ptr, None
+            self._view = _base._view
+
+    def data_ptr(self) -> int:
+        return self._ptr + 4 * self._offset
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            a, b, _ = key.indices(self._n)
+            return host_scalars(b - a, _base=self._owner, _offset=self._offset + a)
+        raise TypeError("host_scalars supports slices only")
+
+    def numpy(self) -> np.ndarray:
+        """a COPY of the current values (call after synchronising the stream that writes them)"""
+        return np.array(self._view[self._offset:self._offset + self._n], dtype=np.float32)
+
+    def __del__(self):
+        if getattr(self, "_lib", None) is not None and self._ptr:
+            try:
+                self._lib.mggcn_free_host(self._ptr)
+            except Exception:
+                pass
+            self._ptr = 0
+
+
 class dn_matrix:
     """Row-major dense matrix, reference src/matrix.hpp:478-639.  ``dtype`` is
     float32 (r_t) or int32 (labels).  ``buffer`` shares storage like the
