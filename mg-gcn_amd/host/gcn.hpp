@@ -572,7 +572,7 @@ public:
 
     void enqueue(context ctx, dn_matrix<r_t> H, dn_matrix<x_t> Y, std::size_t n_global) {
         ctx.set();
-        if (!sums_) sums_ = mggcn::device_malloc<r_t>(2);
+        if (!sums_) sums_ = mggcn::host_malloc<r_t>(2);          // written by the kernels, read by the host after its sync
         if (fused) {
             if (copy) {                       // reference: copy, then in place (:653-656); here the pass writes elsewhere
                 if (!G.buffer()) G = dn_matrix<r_t>(H.n(), H.m());
@@ -612,8 +612,7 @@ public:
         ctx.record(name + "1_loss-layer", 0);
         ctx.register_timer(name + "loss-layer", name + "0_loss-layer", name + "1_loss-layer");
         ctx.sync();
-        r_t s[2];
-        mggcn::download(s, k.sums(), 2);
+        const r_t *s = k.sums();                                 // mapped pinned host memory
         return std::make_pair(s[0] / H.n(), s[1] / H.n());
     }
     auto backward() { return k.gradient(); }
@@ -638,9 +637,7 @@ public:
         ctx.sync();
         r_t loss = 0, acc = 0;
         for (std::size_t i = 0; i < ctx.size(); i++) {          // host sum of the per-GPU scalars (reference :929)
-            r_t s[2];
-            ctx[i].set();
-            mggcn::download(s, ks[i].sums(), 2);
+            const r_t *s = ks[i].sums();                        // mapped pinned host memory
             loss += s[0];
             acc += s[1];
         }

@@ -29,6 +29,15 @@ device_ptr<T> device_malloc(std::size_t count) {
     return device_ptr<T>(p, [](T *q) { mggcn_free(q); });
 }
 
+// mapped pinned host memory (hipHostMalloc: visible to every device at the same address): for the few scalars a kernel
+// reports to the host -- read after a synchronisation without a device-to-host copy
+template <typename T>
+device_ptr<T> host_malloc(std::size_t count) {
+    T *p = count ? static_cast<T *>(mggcn_malloc_host(count * sizeof(T))) : nullptr;
+    for (std::size_t i = 0; i < count; i++) p[i] = T();
+    return device_ptr<T>(p, [](T *q) { mggcn_free_host(q); });
+}
+
 // view into an existing allocation, keeps the owner alive
 template <typename T>
 device_ptr<T> device_view(const device_ptr<T> &owner, std::size_t offset) {
