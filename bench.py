@@ -58,6 +58,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
+    # stdout when its first communicator comes up; gloo prints its rank table): everything this process writes to
+    # file descriptor 1 from here on goes to stderr, and the JSON line goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -237,7 +244,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 def cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d):

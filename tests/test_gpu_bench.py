@@ -1,0 +1,47 @@
+"""bench.py keeps its contract: exactly ONE JSON line on stdout (whatever the libraries print), with the fields the
+driver reads -- at N = 1 and, as a rehearsal over gloo on one GPU, through the N > 1 code path."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _one_json_line(stdout: str) -> dict:
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must hold one line, got {len(lines)}: {lines[:3]}"
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_prints_one_json_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "0.05", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _one_json_line(r.stdout)
+    assert REQUIRED <= set(out) and "cpu_baseline" in out
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is False
+    assert out["value"] > 0 and abs(out["value"] - out["ms_per_step"]) < 1e-9
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["loss_matches_gpu_first"] is True
+    assert out["loss_first_last"][1] < out["loss_first_last"][0]
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_rehearsal_prints_one_json_line():
+    env = dict(os.environ, MGGCN_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _one_json_line(r.stdout)
+    assert REQUIRED <= set(out)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["parallelism"].startswith("rows2")
+    assert out["loss_first_last"][1] < out["loss_first_last"][0]
