@@ -15,7 +15,8 @@ Layout:
 """
 from . import _lib, datasets                                   # noqa: F401
 from ._lib import engine_error                                  # noqa: F401
-from .matrix import context, csr_matrix, dn_matrix, matrix_error  # noqa: F401
+from . import matrix                                            # noqa: F401
+from .matrix import context, csr_matrix, dn_matrix, host_scalars, matrix_error  # noqa: F401
 from . import ops                                               # noqa: F401
 from .ops import get_matmul_buffer, matmul                      # noqa: F401
 from .gcn import (gcn, gcn_layer, linear, softmax, softmax_cross_entropy_loss,  # noqa: F401

@@ -241,6 +241,63 @@ def test_loss_chain_and_fused_loss(pkg, oracle, ctx, n, m):
     assert abs(float(s.item()) - np.abs(H.astype(np.float64)).sum()) <= 1e-5 * np.abs(H).sum()
 
 
+@pytest.mark.parametrize("m", [1, 2, 15, 16, 17, 32, 33, 41, 48, 49, 63, 64, 65, 128, 129])
+def test_fused_loss_widths_out_of_place_and_reproducible(pkg, oracle, ctx, m):
+    """every lanes-per-row / logits-per-lane form of the fused loss (16-lane rows up to 64 classes, a wave per row
+    above), out of place == in place bit for bit, and the two reported scalars bitwise equal from run to run (they
+    are per-workgroup partials summed in a fixed order, no atomics)"""
+    import torch
+    n = 4099                                                  # not a multiple of the rows in flight per wave
+    rng = np.random.default_rng(7 * m + 1)
+    H = (rng.standard_normal((n, m)) * 4).astype(np.float32)
+    H[3, :] = -2.25                                           # full tie: first index wins
+    Y = rng.integers(0, m, size=(n, 1)).astype(np.int32)
+    ls, ac, G, _ = oracle.softmax_cross_entropy(H, Y, n_global=n)
+    Yd = pkg.dn_matrix.from_numpy(Y)
+    runs = []
+    for _ in range(3):
+        Hd, Gd = pkg.dn_matrix.from_numpy(H), pkg.dn_matrix(n, m)
+        sums = torch.zeros(2, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()                              # torch zeroes on its own stream
+        pkg.ops.softmax_xent_fused(ctx, Hd, Yd, 1.0 / n, sums, out=Gd); ctx.sync()
+        np.testing.assert_array_equal(Hd.numpy(), H)          # the logits are left alone
+        runs.append((Gd.numpy().copy(), sums.cpu().numpy().copy()))
+    Hd = pkg.dn_matrix.from_numpy(H)
+    sums = torch.zeros(2, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    pkg.ops.softmax_xent_fused(ctx, Hd, Yd, 1.0 / n, sums); ctx.sync()      # in place
+    np.testing.assert_array_equal(Hd.numpy(), runs[0][0])
+    for g, sm in runs[1:]:
+        np.testing.assert_array_equal(g, runs[0][0])
+        np.testing.assert_array_equal(sm, runs[0][1])          # bitwise: no atomics
+    np.testing.assert_array_equal(sums.cpu().numpy(), runs[0][1])
+    assert relerr(runs[0][0], G) <= TOL
+    assert abs(float(runs[0][1][0]) - ls) <= 1e-4 * abs(ls)
+    assert round(float(runs[0][1][1])) == round(ac)
+
+
+def test_small_memset_kernel_and_host_scalars(pkg, ctx):
+    """mggcn_memset_zero: word-aligned ranges go through the library's own kernel (device memory and mapped pinned host
+    memory), everything else through the runtime; host_scalars are readable after a sync without a copy"""
+    import torch
+    for words in (1, 2, 255, 256, 257, 70000, 300000):
+        t = torch.full((words + 2,), 7.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()                              # torch fills on ITS stream; the memset runs on the context's
+        ctx.lib.mggcn_memset_zero(t.data_ptr() + 4, 4 * words, ctx.stream(0)); ctx.sync()
+        h = t.cpu().numpy()
+        assert h[0] == 7.0 and h[-1] == 7.0 and not h[1:-1].any(), words
+    b = torch.full((16,), 255, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.lib.mggcn_memset_zero(b.data_ptr() + 1, 6, ctx.stream(0)); ctx.sync()          # unaligned: runtime path
+    assert b.cpu().numpy().tolist() == [255] + [0] * 6 + [255] * 9
+    hs = pkg.matrix.host_scalars(4)
+    A = pkg.dn_matrix.from_numpy(np.array([[1.5, -2.5, 4.0]], dtype=np.float32))
+    pkg.ops.abssum(ctx, A, hs[1:2]); ctx.sync()
+    assert hs.numpy().tolist() == [0.0, 8.0, 0.0, 0.0]
+    ctx.lib.mggcn_memset_zero(hs.data_ptr(), 16, ctx.stream(0)); ctx.sync()
+    assert hs.numpy().tolist() == [0.0] * 4
+
+
 def test_adam_fused_equals_chain_equals_oracle(pkg, oracle, ctx):
     for fused in (False, True):
         lin = pkg.linear("0_", 64, 32, True, fused)
