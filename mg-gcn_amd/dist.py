@@ -683,6 +683,7 @@ class dist_row_linear:
         self.G_b.local = dn_matrix(1, out, self.G_flat[off_b:])
         if off_b != in_ * out:
             self.G_flat.zero_()                                # the padding takes part in the sum
+            _torch().cuda.current_stream().synchronize()        # torch zeroes on ITS stream; the kernels run on the context's
         self._grad_pending = None
         self._dctx = dctx
         self.backward_out, self.fused = backward_out, fused
