@@ -385,50 +385,71 @@ __global__ __launch_bounds__(NT, 4) void gemm_mfma_kernel(   // 4 waves per SIMD
 
     MGGCN_GEMM_STAMP(7);
     // epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // One block-uniform choice of what happens to the value, then per 32x32 block: the 16 auxiliary reads (old C for
-    // beta != 0, Z for the leaky-ReLU mask) are all issued before the first is consumed, and an element's address is
-    // the lane's block corner + a wave-uniform (r-dependent) offset.  (First version: epilogue_value() per element --
-    // a 64-bit multiply, three branches and, with a mask or beta, one full memory round trip per element, 32 in a row.)
+    // The kind of epilogue and "is this tile interior" are block-uniform and become COMPILE-TIME parameters of the code
+    // that runs (eight straight-line variants): per 32x32 block the 16 auxiliary reads (old C for beta != 0, Z for the
+    // leaky-ReLU mask) are issued together, then 16 stores back to back; an element's address is the lane's block corner
+    // plus a wave-uniform offset.  History: (1) epilogue_value() per element -- a 64-bit multiply, three branches and, with
+    // a mask or beta, a memory round trip per element; (2) the kind as a run-time value inside the unrolled loops -- the
+    // compiler merged the paths' outstanding loads and put s_waitcnt vmcnt(0) around EVERY store: 32 dependent memory
+    // round trips per wave, 24-30 k cycles, 45 % of a wave's life at K = 128 (gemm_timeline, r02).
     const bool to_slab = gridDim.z > 1;
     float *out = to_slab ? slab + (size_t)blockIdx.z * (M + (epi.colsum ? 1 : 0)) * N : C;
     const size_t ldo = to_slab ? (size_t)N : ldc;
     enum { kPlain, kBias, kMask, kBeta };
     const int kind = to_slab ? kPlain : epi.bias ? kBias : epi.mask ? kMask : beta != 0.f ? kBeta : kPlain;
     const float scale = to_slab ? 1.f : alpha;
+    auto emit = [&](auto kind_c, auto full_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool FULL = decltype(full_c)::value;          // every row and column of the tile is inside C
 #pragma unroll
-    for (int i = 0; i < MI; i++)
+        for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int j = 0; j < NI; j++) {
-            const long long col = n0 + wn * (BN / WN) + j * 32 + l31;
-            const long long row0 = m0 + wm * (BM / WM) + i * 32 + 4 * lhi;
-            if (col >= N) continue;
-            float *corner = out + (size_t)row0 * ldo + col;
-            const long long rows_left = (long long)M - row0;          // element r is in range iff its row offset < rows_left
-            float aux[16];
-            if (kind == kMask || kind == kBeta) {
-                const float *src = kind == kMask ? epi.mask + (size_t)row0 * epi.ldz + col : corner;
-                const size_t lds = kind == kMask ? epi.ldz : ldo;
+            for (int j = 0; j < NI; j++) {
+                const long long col = n0 + wn * (BN / WN) + j * 32 + l31;
+                const long long row0 = m0 + wm * (BM / WM) + i * 32 + 4 * lhi;
+                const bool col_ok = FULL || col < (long long)N;
+                const long long rows_left = (long long)M - row0;      // element r is in range iff its row offset < rows_left
+                float *corner = out + (size_t)row0 * ldo + col;      // (only dereferenced where the element exists)
+                float aux[16];
+                if constexpr (KIND == kMask || KIND == kBeta) {
+                    const float *src = KIND == kMask ? epi.mask + (size_t)row0 * epi.ldz + col : corner;
+                    const size_t lds = KIND == kMask ? epi.ldz : ldo;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        aux[r] = (FULL || (col_ok && ro < rows_left)) ? src[(size_t)ro * lds] : 0.f;
+                    }
+                }
+                float bias = 0.f;
+                if constexpr (KIND == kBias) bias = col_ok ? epi.bias[col] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int ro = (r & 3) + 8 * (r >> 2);
-                    aux[r] = ro < rows_left ? src[(size_t)ro * lds] : 0.f;
+                    const float av = scale * acc[i][j][r];
+                    float v = av;
+                    // bias: the row vector the reference broadcasts into C before its beta = 1 sgemm (src/gcn.hpp:116-123),
+                    // same single rounding as fmaf(1, bias, alpha*v); mask: leaky_relu_backward of the consumer
+                    // (src/cuda_utils.cu:33-38) on the value a beta = 0 GEMM would store
+                    if constexpr (KIND == kBias) v = fmaf(1.f, bias, av);
+                    if constexpr (KIND == kMask) v = aux[r] > 0.f ? av : epi.slope * av;
+                    if constexpr (KIND == kBeta) v = fmaf(beta, aux[r], av);
+                    if (FULL || (col_ok && ro < rows_left)) corner[(size_t)ro * ldo] = v;
                 }
             }
-            const float bias = kind == kBias ? epi.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int ro = (r & 3) + 8 * (r >> 2);
-                const float av = scale * acc[i][j][r];
-                float v = av;
-                // bias: the row vector the reference broadcasts into C before its beta = 1 sgemm (src/gcn.hpp:116-123),
-                // same single rounding as fmaf(1, bias, alpha*v); mask: leaky_relu_backward of the consumer
-                // (src/cuda_utils.cu:33-38) on the value a beta = 0 GEMM would store
-                if (kind == kBias) v = fmaf(1.f, bias, av);
-                else if (kind == kMask) v = aux[r] > 0.f ? av : epi.slope * av;
-                else if (kind == kBeta) v = fmaf(beta, aux[r], av);
-                if (ro < rows_left) corner[(size_t)ro * ldo] = v;
-            }
-        }
+    };
+    using std::integral_constant;
+    const bool tile_full = m0 + BM <= (long long)M && n0 + BN <= (long long)N;      // block-uniform
+    if (tile_full) {
+        if (kind == kPlain) emit(integral_constant<int, kPlain>{}, std::true_type{});
+        else if (kind == kBias) emit(integral_constant<int, kBias>{}, std::true_type{});
+        else if (kind == kMask) emit(integral_constant<int, kMask>{}, std::true_type{});
+        else emit(integral_constant<int, kBeta>{}, std::true_type{});
+    } else {
+        if (kind == kPlain) emit(integral_constant<int, kPlain>{}, std::false_type{});
+        else if (kind == kBias) emit(integral_constant<int, kBias>{}, std::false_type{});
+        else if (kind == kMask) emit(integral_constant<int, kMask>{}, std::false_type{});
+        else emit(integral_constant<int, kBeta>{}, std::false_type{});
+    }
     MGGCN_GEMM_STAMP(8);
 }
 
