@@ -38,6 +38,7 @@
 #include <cstring>
 #include <queue>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "spmm_internal.h"
@@ -425,46 +426,64 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
         }
         MGGCN_PLANES_FOLD(cur_row, acc);
 
-        // Epilogue, four rows at a time: add the two half-waves' partial rows, THEN issue the four
-        // reads of C (beta != 0: every column slice after the first) together, then combine and store.
-        // Row by row the read of row r+1 may not pass the store of row r (same pointer): sixteen
-        // dependent HBM round trips per task.  (Worth 0.5 % here -- the other waves hide most of it.)
-        auto emit4 = [&](uint32_t r0, float (&x)[4][4]) {
+        // Epilogue, four rows at a time, in three phases with nothing else between the memory operations of a phase:
+        // (1) the four reads of C (beta != 0: every column slice after the first), (2) all four results, (3) the four stores.
+        // vmcnt counts loads AND stores in order: written row by row (read, combine, store, next row) every row was a
+        // dependent memory round trip -- and with the stores inside the per-row branches the compiler put s_waitcnt vmcnt(0)
+        // in front of each of them even at beta = 0: sixteen serial round trips at the END of every wave, when no other
+        // wave is left to hide them (r02: the same pattern cost the GEMM epilogue 45 % of a wave's life at K = 128).
+        // (beta != 0 is a compile-time parameter of the code that runs: with the reads of C merely predicated the
+        //  compiler still waited vmcnt(0) in front of every group's loads -- i.e. for the previous group's stores)
+        // the row table comes out of its VGPR once, before the first store: a v_readlane of a loaded value in front of
+        // every group made the compiler wait vmcnt(0) there -- for the previous group's stores
+        uint32_t dst_all[kRW];
+#pragma unroll
+        for (int r = 0; r < kRW; r++) dst_all[r] = __builtin_amdgcn_readlane(my_dst, r);
+        auto emit4_any = [&](auto has_beta_c, uint32_t r0, float (&x)[4][4]) {
+            constexpr bool HAS_BETA = decltype(has_beta_c)::value;
             if (r0 >= task.n_rows) return;                                   // wave-uniform
 #pragma unroll
             for (int k = 0; k < 4; k++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) x[k][c] += __shfl_xor(x[k][c], 32);
-            uint32_t dst[4];
-            float4 c0[4];
             const bool writer = active && !hmask;
+            uint32_t dst[4];
+            bool use[4], slot[4];
+            float4 c0[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                dst[k] = __builtin_amdgcn_readlane(my_dst, (int)(r0 + k) & 15);   // wave-uniform
+            for (int k = 0; k < 4; k++) {                                    // (1)
+                dst[k] = dst_all[(r0 + k) & 15];                                  // wave-uniform
+                use[k] = r0 + k < task.n_rows;
+                slot[k] = (dst[k] & kSlotFlag) != 0;
                 c0[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r0 + k < task.n_rows && !(dst[k] & kSlotFlag) && beta != 0.f && writer)
-                    c0[k] = *reinterpret_cast<const float4 *>(C + (size_t)dst[k] * ldc + col);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (r0 + k >= task.n_rows || !writer) continue;
-                float4 s = make_float4(x[k][0], x[k][1], x[k][2], x[k][3]);
-                if (dst[k] & kSlotFlag) {
-                    *reinterpret_cast<float4 *>(partial + (size_t)(dst[k] & ~kSlotFlag) * d + col) = s;
-                    continue;
+                if constexpr (HAS_BETA) {
+                    if (use[k] && !slot[k] && writer)
+                        c0[k] = *reinterpret_cast<const float4 *>(C + (size_t)dst[k] * ldc + col);
                 }
-                s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha;
-                if (beta != 0.f) {
-                    s.x = fmaf(beta, c0[k].x, s.x); s.y = fmaf(beta, c0[k].y, s.y);
-                    s.z = fmaf(beta, c0[k].z, s.z); s.w = fmaf(beta, c0[k].w, s.w);
+            }
+            float4 res[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {                                    // (2)
+                float4 f = make_float4(alpha * x[k][0], alpha * x[k][1], alpha * x[k][2], alpha * x[k][3]);
+                if constexpr (HAS_BETA) {
+                    f.x = fmaf(beta, c0[k].x, f.x); f.y = fmaf(beta, c0[k].y, f.y);
+                    f.z = fmaf(beta, c0[k].z, f.z); f.w = fmaf(beta, c0[k].w, f.w);
                 }
                 if (flags & MGGCN_SPMM_LEAKY_RELU) {
-                    s.x = lrelu(s.x, slope); s.y = lrelu(s.y, slope); s.z = lrelu(s.z, slope); s.w = lrelu(s.w, slope);
+                    f.x = lrelu(f.x, slope); f.y = lrelu(f.y, slope); f.z = lrelu(f.z, slope); f.w = lrelu(f.w, slope);
                 }
-                *reinterpret_cast<float4 *>(C + (size_t)dst[k] * ldc + col) = s;
+                // a slice of a heavy row keeps its raw partial sum (combined, scaled and activated by sweep_combine_kernel)
+                res[k] = slot[k] ? make_float4(x[k][0], x[k][1], x[k][2], x[k][3]) : f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {                                    // (3)
+                float *p = slot[k] ? partial + (size_t)(dst[k] & ~kSlotFlag) * d + col : C + (size_t)dst[k] * ldc + col;
+                if (use[k] && writer) *reinterpret_cast<float4 *>(p) = res[k];
             }
         };
-        MGGCN_PLANES_EMIT_FOURS(emit4)
+        auto emit4_beta = [&](uint32_t r0, float (&x)[4][4]) { emit4_any(std::true_type{}, r0, x); };
+        auto emit4_nobeta = [&](uint32_t r0, float (&x)[4][4]) { emit4_any(std::false_type{}, r0, x); };
+        if (beta != 0.f) { MGGCN_PLANES_EMIT_FOURS(emit4_beta) } else { MGGCN_PLANES_EMIT_FOURS(emit4_nobeta) }
     }
     if (stamps) {                                       // wave-uniform
         uint32_t xcc, hw;
@@ -611,31 +630,56 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
     }
     MGGCN_PLANES_FOLD(cur_row, acc);
 
-    auto emit = [&](uint32_t r, float x0, float x1, float x2, float x3) {
-        if (r >= task.n_rows) return;                                    // wave-uniform
-        x0 = reduce_groups<LPE>(x0); x1 = reduce_groups<LPE>(x1);
-        x2 = reduce_groups<LPE>(x2); x3 = reduce_groups<LPE>(x3);
-        if (!active || grp) return;
-        const uint32_t dst = task_rows[(size_t)t * kRW + r];
-        const float xs[4] = {x0, x1, x2, x3};
-        if (dst & kSlotFlag) {
-            float *pp = partial + (size_t)(dst & ~kSlotFlag) * d + col;
+    // four rows at a time, three phases (reads of C, results, stores) -- see the pair kernel's epilogue
+    auto emit4_any = [&](auto has_beta_c, uint32_t r0, float (&x)[4][4]) {
+        constexpr bool HAS_BETA = decltype(has_beta_c)::value;
+        if (r0 >= task.n_rows) return;                                   // wave-uniform
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (col + k < d) pp[k] = xs[k];
-            return;
-        }
-        float *cp = C + (size_t)dst * ldc + col;
+        for (int k = 0; k < 4; k++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (col + k >= d) continue;
-            float o = alpha * xs[k];
-            if (beta != 0.f) o = fmaf(beta, cp[k], o);
-            if (flags & MGGCN_SPMM_LEAKY_RELU) o = lrelu(o, slope);
-            cp[k] = o;
+            for (int c = 0; c < 4; c++) x[k][c] = reduce_groups<LPE>(x[k][c]);
+        const bool writer = active && grp == 0;
+        // with reads of C: two rows per pass (the kernel has 64 VGPRs to itself; four rows' old values spilled at LPE = 12)
+        constexpr int STEP = HAS_BETA ? 2 : 4;
+#pragma unroll
+        for (int k0 = 0; k0 < 4; k0 += STEP) {
+            uint32_t dst[STEP];
+            bool use[STEP], slot[STEP];
+            float old[STEP][4];
+#pragma unroll
+            for (int q = 0; q < STEP; q++) {                                 // (1)
+                use[q] = r0 + k0 + q < task.n_rows;
+                dst[q] = use[q] ? task_rows[(size_t)t * kRW + r0 + k0 + q] : 0u;
+                slot[q] = (dst[q] & kSlotFlag) != 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    old[q][c] = 0.f;
+                    if constexpr (HAS_BETA) {
+                        if (use[q] && !slot[q] && writer && col + c < d) old[q][c] = C[(size_t)dst[q] * ldc + col + c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < STEP; q++)                                   // (2), in place
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float o = alpha * x[k0 + q][c];
+                    if constexpr (HAS_BETA) o = fmaf(beta, old[q][c], o);
+                    if (flags & MGGCN_SPMM_LEAKY_RELU) o = lrelu(o, slope);
+                    x[k0 + q][c] = slot[q] ? x[k0 + q][c] : o;
+                }
+#pragma unroll
+            for (int q = 0; q < STEP; q++) {                                 // (3)
+                float *p = slot[q] ? partial + (size_t)(dst[q] & ~kSlotFlag) * d + col : C + (size_t)dst[q] * ldc + col;
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (use[q] && writer && col + c < d) p[c] = x[k0 + q][c];
+            }
         }
     };
-    MGGCN_PLANES_EMIT_ALL(emit)
+    auto emit4_beta = [&](uint32_t r0, float (&x)[4][4]) { emit4_any(std::true_type{}, r0, x); };
+    auto emit4_nobeta = [&](uint32_t r0, float (&x)[4][4]) { emit4_any(std::false_type{}, r0, x); };
+    if (beta != 0.f) { MGGCN_PLANES_EMIT_FOURS(emit4_beta) } else { MGGCN_PLANES_EMIT_FOURS(emit4_nobeta) }
 }
 
 __global__ __launch_bounds__(256) void sweep_combine_kernel(
