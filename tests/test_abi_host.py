@@ -255,6 +255,50 @@ def test_reserved_accumulator_registers_are_left_alone_by_the_compiler(tmp_path)
     assert checked == 5, checked
 
 
+def _longest_store_run(body: str, store_re: str) -> int:
+    """longest run of store instructions with no s_waitcnt ... vmcnt between two of them"""
+    best = cur = 0
+    for line in body.split("\n"):
+        st = line.split(";")[0].strip()
+        if re.match(store_re, st):
+            cur += 1
+            best = max(best, cur)
+        elif re.match(r"s_waitcnt\b.*vmcnt", st):
+            cur = 0
+    return best
+
+
+def test_epilogues_issue_their_stores_back_to_back(tmp_path):
+    """vmcnt counts stores: an epilogue whose stores sit inside per-element / per-row branches gets s_waitcnt vmcnt(0)
+    in front of each of them from the compiler -- every store a dependent memory round trip (r02: 45 % of a GEMM wave's
+    life at K = 128, sixteen serial round trips at the end of every SpMM wave).  Guard the straight-line forms: somewhere
+    in each hot kernel a whole block's stores are issued with no vmcnt wait between them."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    want = {
+        "spmm_sweep.hip": [(r"spmm_sweep_pair_kernel", r"global_store_dwordx4\b", 12),
+                           (r"spmm_sweep_quad_lds_kernelILi16E", r"global_store_dword\b", 48)],
+        "gemm.hip": [(r"gemm_mfma_kernelILb1ELb0ELi128ELi512ELb1E", r"global_store_dword\b", 16),
+                     (r"gemm_mfma_kernelILb1ELb1ELi128ELi512ELb1E", r"global_store_dword\b", 16),
+                     (r"gemm_mfma_kernelILb0ELb0ELi128ELi512ELb1E", r"global_store_dword\b", 16)],
+    }
+    for fname, kernels in want.items():
+        out = tmp_path / (fname + ".s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                            "-S", "--cuda-device-only", os.path.join(ROOT, "mg-gcn_amd", "csrc", fname), "-o", str(out)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text = out.read_text()
+        for pat, store_re, least in kernels:
+            bodies = re.findall(r"^(_Z\S*%s[^\s:]*):[^\n]*\n(.*?)s_endpgm" % pat, text, flags=re.S | re.M)
+            assert bodies, pat
+            for name, body in bodies:
+                run = _longest_store_run(body, store_re)
+                assert run >= least, f"{name}: longest run of stores without a vmcnt wait is {run} (< {least})"
+
+
 def test_comm_library_exports_every_declared_symbol():
     """include/mggcn_comm.h (the single-process multi-GPU exchange the C++ host layer links): every
     declared entry point is exported by libmggcn_comm.so.  Symbols are read from the ELF dynamic
