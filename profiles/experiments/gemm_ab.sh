@@ -12,7 +12,7 @@ for round in 1 2; do
   i=0
   for flags in "$@"; do
     echo "== variant $i: ${flags:-default} (round $round)"
-    timeout -k 5 60 /tmp/gemm_ab_$i 232968 608 0 20 && timeout -k 5 60 /tmp/gemm_ab_$i 232968 128 0 20 && timeout -k 5 60 /tmp/gemm_ab_$i 608 232968 1 20 && timeout -k 5 60 /tmp/gemm_ab_$i 128 232968 1 20 || exit 1
+    timeout -k 5 60 /tmp/gemm_ab_$i 232968 608 0 40 && timeout -k 5 60 /tmp/gemm_ab_$i 232968 128 0 40 && timeout -k 5 60 /tmp/gemm_ab_$i 608 232968 1 40 && timeout -k 5 60 /tmp/gemm_ab_$i 128 232968 1 40 && timeout -k 5 60 /tmp/gemm_ab_$i 232968 128 0 40 41 && timeout -k 5 60 /tmp/gemm_ab_$i 128 232968 1 40 41 || exit 1
     i=$((i+1))
   done
 done

@@ -42,7 +42,7 @@ __device__ unsigned long long *g_stamps;
 #include "gemm.hip"
 
 int main(int argc, char **argv) {
-    const uint32_t M = argc > 1 ? atoi(argv[1]) : 232968, K = argc > 2 ? atoi(argv[2]) : 608, N = 128;
+    const uint32_t M = argc > 1 ? atoi(argv[1]) : 232968, K = argc > 2 ? atoi(argv[2]) : 608, N = argc > 5 ? atoi(argv[5]) : 128;
     const int trans_a = argc > 3 ? atoi(argv[3]) : 0;           // 1: A is stored [K x M] (the X^T G product)
     float *A, *B, *C;
     const size_t na = (size_t)M * K, nb = (size_t)K * N, nc = (size_t)M * N;
