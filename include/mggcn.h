@@ -128,6 +128,13 @@ uint32_t mggcn_spmm_plan_num_sweep_tasks(const mggcn_spmm_plan *plan); /* 0: no 
 uint32_t mggcn_spmm_plan_num_launches(const mggcn_spmm_plan *plan, uint32_t d); /* kernel launches per SpMM call at width d */
 size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan);
 uint32_t mggcn_spmm_plan_num_slices(const mggcn_spmm_plan *plan);      /* column slices of the sweep form (0: none) */
+/* One line of text with what the plan builder measured and decided: form (rowsplit / sweep / sweep-narrow), share of the
+ * non-zeros in the 1 % most popular columns and the flag derived from it, mean (panel,row) run length, column slices,
+ * device bytes, host build seconds, then per slice: tasks, launch rounds, panel rows, run padding, lanes per entry,
+ * padded entry count.  snprintf semantics (returns the length written).  MGGCN_SPMM_PLAN_LOG=1 in the environment
+ * prints the same line to stderr whenever a plan is created.  The tuning knobs (MGGCN_SPMM_*) are read once, here,
+ * never on the launch path. */
+int mggcn_spmm_plan_describe(const mggcn_spmm_plan *plan, char *out, size_t cap);
 /* diagnostics: with MGGCN_SPMM_STAMPS=1 in the environment at plan creation the d >= 96 sweep kernel records, per
  * one-wave task of column slice `slice`, {start, end} on the 100 MHz constant clock and {HW_ID << 32 | blockIdx << 4 | XCC id} of
  * its LAST launch; this copies them out (3 x u64 per task, blocking) and returns the task count.  Never set in a

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "mggcn_spmm_plan_num_launches": (c_uint32, [vp, c_uint32]),
     "mggcn_spmm_plan_bytes": (c_size_t, [vp]),
     "mggcn_spmm_plan_num_slices": (c_uint32, [vp]),
+    "mggcn_spmm_plan_describe": (c_int, [vp, ctypes.c_char_p, c_size_t]),
     "mggcn_spmm_plan_read_stamps": (c_uint32, [vp, c_uint32, vp, c_uint32]),
     "mggcn_spmm_csr_f32": (None, [vp, vp, c_uint32, c_uint32, vp, vp, vp, vp, c_size_t, vp, c_size_t,
                                   c_uint32, c_float, c_float, c_uint32, c_float]),

@@ -31,6 +31,9 @@
 #include <vector>
 
 #include "common.h"
+#include <chrono>
+#include <cstdio>
+
 #include "spmm_internal.h"
 
 namespace {
@@ -265,6 +268,13 @@ struct mggcn_spmm_plan {
     // narrow form (d_hint <= 64): scratch for B re-pitched to 64-byte-multiple rows, n_cols x bpad_dp floats
     float *d_bpad = nullptr;
     uint32_t bpad_dp = 0;
+    // what the plan builder decided (mggcn_spmm_plan_describe)
+    uint32_t d_hint = 0;
+    int hot_columns = -1;          // -1: not measured (no sweep form considered)
+    double hot_share = 0.0;        // share of the non-zeros in the 1 % most popular columns
+    double mean_run = 0.0;         // mean (panel,row) run length the density gate saw
+    double build_s = 0.0;          // host seconds spent in plan_create (sort + upload)
+    uint64_t nnz = 0;
 };
 
 MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,
@@ -283,6 +293,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
     const bool narrow = d_hint >= 1 && d_hint <= 64 && n_cols <= (1u << 24);
     if (!narrow) d_hint = 0;
     MGGCN_REQUIRE(max_d > 0, "max_d must be positive");
+    const auto t_build0 = std::chrono::steady_clock::now();
     // slice length for heavy rows; rows up to 1.5x the slice stay whole
     const uint32_t split = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_SPLIT", 512u));
 
@@ -358,6 +369,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
             uint64_t hot = 0;
             for (size_t k = 0; k < top; k++) hot += cc[k];
             hot_columns = (double)hot >= 0.05 * (double)(nz1 - nz0);
+            plan->hot_share = nz1 > nz0 ? (double)hot / (double)(nz1 - nz0) : 0.0;
         }
         if (const char *hc = std::getenv("MGGCN_SPMM_HOT_COLUMNS")) hot_columns = std::atoi(hc) != 0;
         const uint64_t slice_rows = std::max<uint64_t>(
@@ -373,6 +385,8 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         const double panel_rows = sweep_panel_rows(d_hint, hot_columns);
         const double mean_run = n_cols ? avg_deg * std::min<double>(panel_rows, n_cols) / n_cols : 0.0;
         if (!std::getenv("MGGCN_SPMM_SLICE_ROWS")) S = std::max<uint32_t>(1u, std::min<uint32_t>(S, (uint32_t)(avg_deg / 64.0)));
+        plan->hot_columns = hot_columns ? 1 : 0;
+        plan->mean_run = mean_run;
         const bool worth_it = total_nnz >= env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20) &&   // small graphs: row-split is fine
                               mean_run * 10.0 >= env_u32("MGGCN_SPMM_SWEEP_MIN_RUN_X10", 20u);
         if (!worth_it) {
@@ -421,7 +435,39 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
             plan->bytes += bb;
         }
     }
+    plan->d_hint = d_hint;
+    plan->nnz = n_rows ? (uint64_t)host_indptr[n_rows] - host_indptr[0] : 0;
+    plan->build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build0).count();
+    if (env_u32("MGGCN_SPMM_PLAN_LOG", 0u)) {
+        char line[2048];
+        mggcn_spmm_plan_describe(plan, line, sizeof line);
+        std::fprintf(stderr, "[mggcn plan] %s\n", line);
+    }
     return plan;
+}
+
+// Human-readable record of the plan builder's decisions (one line; sweep slices separated by " | "): which form,
+// the column-popularity measurement and flag, panel rows, slices, lanes per entry, tasks / rounds per slice, padded
+// entry stream, device bytes, host build time.  Returns the length written (snprintf semantics).
+MGGCN_API int mggcn_spmm_plan_describe(const mggcn_spmm_plan *plan, char *out, size_t cap) {
+    if (!plan || !out || !cap) return 0;
+    size_t at = 0;
+    auto put = [&](const char *fmt, auto... a) {
+        if (at + 1 >= cap) return;
+        const int k = std::snprintf(out + at, cap - at, fmt, a...);
+        if (k > 0) at = std::min(cap - 1, at + (size_t)k);
+    };
+    put("rows=%u cols=%u nnz=%llu max_d=%u d_hint=%u form=%s hot_share=%.3f hot_columns=%d mean_run=%.2f slices=%zu bytes=%zu build_s=%.3f",
+        plan->n_rows, plan->n_cols, (unsigned long long)plan->nnz, plan->max_d, plan->d_hint,
+        plan->sweeps.empty() ? "rowsplit" : (plan->d_bpad ? "sweep-narrow" : "sweep"), plan->hot_share, plan->hot_columns,
+        plan->mean_run, plan->sweeps.size(), mggcn_spmm_plan_bytes(plan), plan->build_s);
+    if (plan->sweeps.empty()) put(" items=%u split_rows=%u", plan->n_items, plan->n_split_rows);
+    for (auto *sp : plan->sweeps) {
+        char one[256];
+        sweep_plan_describe(sp, one, sizeof one);
+        put(" | %s", one);
+    }
+    return (int)at;
 }
 
 MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {

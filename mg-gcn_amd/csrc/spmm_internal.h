@@ -20,6 +20,7 @@ bool sweep_wants_repack(const SweepPlan *p, uint32_t d, size_t ldb, const void *
 void sweep_repack(hipStream_t st, const float *B, size_t ldb, uint32_t n_cols, uint32_t d, float *out, uint32_t dp);
 void sweep_plan_destroy(SweepPlan *p);
 size_t sweep_plan_bytes(const SweepPlan *p);
+int sweep_plan_describe(const SweepPlan *p, char *out, size_t cap);   // one line: tasks, rounds, panel rows, lpe, entries
 uint32_t sweep_plan_tasks(const SweepPlan *p);
 uint32_t sweep_plan_split_rows(const SweepPlan *p);
 uint32_t sweep_plan_read_stamps(const SweepPlan *p, unsigned long long *host_out, uint32_t capacity_tasks);

@@ -746,6 +746,12 @@ struct SweepPlan {
     float *d_partial = nullptr;
     unsigned long long *d_stamps = nullptr;   // diagnostics: 3 words per task (MGGCN_SPMM_STAMPS=1)
     size_t bytes = 0;
+    // tuning knobs, read from the environment ONCE when the plan is built (never on the launch path)
+    uint32_t panel_rows = 0;
+    uint64_t n_entries = 0;        // padded entry stream length
+    uint32_t prio_bits_wide = 0, prio_bits_narrow = 0;   // kFlagPrioRotate | shift << kPrioShiftPos, or 0
+    uint32_t tasks_per_wave = 1;
+    bool allow_quad = true, allow_vec4 = true;
 };
 
 SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
@@ -955,6 +961,15 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     p->n_rows = n_rows; p->n_cols = n_cols; p->max_d = max_d;
     p->n_tasks = T; p->round_tasks = round_tasks; p->run_pad = G; p->lpe = lpe;
     p->n_split_rows = (uint32_t)split_rows.size(); p->n_slots = n_slots;
+    p->panel_rows = panel_rows; p->n_entries = off;
+    {   // priority rotation (float4 kernels; see rotate_priority): period 2^8 entries / every chunk of the narrow stream
+        const uint32_t rot = env_u32("MGGCN_SPMM_PRIO_ROTATE", 1u) ? kFlagPrioRotate : 0u;
+        p->prio_bits_wide = rot | (std::min(env_u32("MGGCN_SPMM_PRIO_SHIFT", 8u), 15u) << kPrioShiftPos);
+        p->prio_bits_narrow = rot | (std::min(env_u32("MGGCN_SPMM_PRIO_SHIFT_NARROW", 1u), 15u) << kPrioShiftPos);
+        p->tasks_per_wave = std::max(1u, env_u32("MGGCN_SPMM_TASKS_PER_WAVE", 1u));
+        p->allow_quad = env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) != 0;
+        p->allow_vec4 = env_u32("MGGCN_SPMM_SWEEP_VEC4", 1u) != 0;
+    }
     const size_t tb = tasks.size() * sizeof(SweepTask), eb = entries.size() * sizeof(uint2);
     const size_t rb = task_rows.size() * sizeof(uint32_t), sb = split_rows.size() * sizeof(SweepSplitRow);
     const size_t pb = (size_t)n_slots * max_d * sizeof(float);
@@ -990,6 +1005,14 @@ void sweep_plan_destroy(SweepPlan *p) {
 }
 
 size_t sweep_plan_bytes(const SweepPlan *p) { return p ? p->bytes : 0; }
+
+// one line per slice plan for MGGCN_SPMM_PLAN_LOG / mggcn_spmm_plan_describe
+int sweep_plan_describe(const SweepPlan *p, char *out, size_t cap) {
+    if (!p) return 0;
+    return std::snprintf(out, cap, "tasks=%u rounds=%u panel_rows=%u run_pad=%u lpe=%u entries=%llu split_rows=%u slots=%u",
+                         p->n_tasks, (p->n_tasks + p->round_tasks - 1) / p->round_tasks, p->panel_rows, p->run_pad, p->lpe,
+                         (unsigned long long)p->n_entries, p->n_split_rows, p->n_slots);
+}
 uint32_t sweep_plan_tasks(const SweepPlan *p) { return p ? p->n_tasks : 0; }
 uint32_t sweep_plan_split_rows(const SweepPlan *p) { return p ? p->n_split_rows : 0; }
 
@@ -1006,7 +1029,7 @@ uint32_t sweep_plan_launches(const SweepPlan *p, uint32_t d) {
     const bool quad = p->lpe && d <= 4 * p->lpe;
     const bool vec4 = p->run_pad % 2 == 0 && d >= 96 && d % 4 == 0;
     const bool vec2 = d > 64 && d % 2 == 0;
-    const uint32_t tpw = (vec4 && !quad) ? std::max(1u, env_u32("MGGCN_SPMM_TASKS_PER_WAVE", 1u)) : 1u;
+    const uint32_t tpw = (vec4 && !quad) ? p->tasks_per_wave : 1u;
     const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks * tpw : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
     return (p->n_tasks + per_launch - 1) / per_launch + (p->n_split_rows ? 1u : 0u);
 }
@@ -1021,7 +1044,7 @@ bool sweep_supports(const SweepPlan *p, uint32_t d, size_t ldb, size_t ldc, cons
 }
 
 bool sweep_wants_repack(const SweepPlan *p, uint32_t d, size_t ldb, const void *B) {
-    if (!p || !p->lpe || d > 4 * p->lpe || env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) == 0) return false;
+    if (!p || !p->lpe || d > 4 * p->lpe || !p->allow_quad) return false;
     // The gather path is priced per 128-byte line touched (~2.7 cycles each, narrow_spmm.py: 16 rows of
     // 64 B per instruction cost 62 cycles, 4 rows of 176 B 26): a 176-byte pitch puts 37 % of the rows
     // on three lines, a pitch that is a multiple of 64 B never more than two.
@@ -1039,12 +1062,11 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
                   uint32_t d, float alpha, float beta, uint32_t flags, float slope) {
     // narrow rows on a quad-padded stream: B must be 16-byte pitched (the caller re-pitches it
     // with sweep_repack when sweep_wants_repack says so)
-    const bool quad = p->lpe && d <= 4 * p->lpe && ldb % 4 == 0 && aligned16(B) &&
-                      env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) != 0;
+    const bool quad = p->lpe && d <= 4 * p->lpe && ldb % 4 == 0 && aligned16(B) && p->allow_quad;
     // float4 pair form: 16-byte aligned rows of >= 96 columns (narrower rows would idle most of
     // a half-wave); float2 lanes need 8-byte aligned rows; otherwise one column per lane
     const bool vec4 = p->run_pad % 2 == 0 && d >= 96 && d % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && aligned16(B) && aligned16(C) &&
-                      env_u32("MGGCN_SPMM_SWEEP_VEC4", 1u) != 0;
+                      p->allow_vec4;
     const bool vec2 = d > 64 && d % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 &&
                       (reinterpret_cast<uintptr_t>(B) & 7u) == 0 && (reinterpret_cast<uintptr_t>(C) & 7u) == 0;
     const uint32_t b_bytes = (uint32_t)((uint64_t)p->n_cols * ldb * sizeof(float));
@@ -1053,16 +1075,15 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
     // waves per CU; six blocks per launch left a third of the waves queued behind the others and out
     // of step: d = 41 1.64 / 1.71 ms against 1.52 / 1.55).  The one-column-per-lane kernels (56 VGPRs)
     // are instruction-bound and take six blocks per CU (d = 41: 2.4 -> 2.0 ms).
-    const uint32_t tpw = (vec4 && !quad) ? std::max(1u, env_u32("MGGCN_SPMM_TASKS_PER_WAVE", 1u)) : 1u;
+    const uint32_t tpw = (vec4 && !quad) ? p->tasks_per_wave : 1u;
     const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks * tpw : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
+    // the knobs (priority rotation, tasks per wave, kernel gates) were read once, when the plan was built
+    const uint32_t wide_flags = (flags & 0xFFu) | p->prio_bits_wide;
+    const uint32_t narrow_flags = (flags & 0xFFu) | p->prio_bits_narrow;
     for (uint32_t t0 = 0; t0 < p->n_tasks; t0 += per_launch) {
         const uint32_t n_launch = std::min(per_launch, p->n_tasks - t0);
         const uint32_t n_waves = tpw > 1 ? std::min(n_launch, p->round_tasks) : n_launch;
         const dim3 grid((n_waves + kWavesPerBlock - 1) / kWavesPerBlock), block(64 * kWavesPerBlock);
-        // priority rotation (float4 kernels; see rotate_priority): period 2^8 entries / every chunk of the narrow stream
-        const uint32_t rot = env_u32("MGGCN_SPMM_PRIO_ROTATE", 1u) ? kFlagPrioRotate : 0u;
-        const uint32_t wide_flags = (flags & 0xFFu) | rot | (std::min(env_u32("MGGCN_SPMM_PRIO_SHIFT", 8u), 15u) << kPrioShiftPos);
-        const uint32_t narrow_flags = (flags & 0xFFu) | rot | (std::min(env_u32("MGGCN_SPMM_PRIO_SHIFT_NARROW", 1u), 15u) << kPrioShiftPos);
 #define MGGCN_LAUNCH_NARROW(L)                                                                             \
     hipLaunchKernelGGL((spmm_sweep_quad_lds_kernel<L>), grid, block, 0, st, p->d_tasks, t0, n_launch, p->d_entries, \
                        p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d, alpha, beta, narrow_flags, slope)

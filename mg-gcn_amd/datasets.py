@@ -178,20 +178,99 @@ def synth_powerlaw_csr(n: int, nnz_target: int, max_deg: int, seed: int = 1, alp
     return indptr.astype(np.uint32), indices, data
 
 
+def synth_symmetric_powerlaw_csr(n: int, nnz_target: int, max_deg: int, seed: int = 1, alpha: float = 1.3):
+    """Reddit's STRUCTURE, not only its shape: an undirected simple graph stored in both directions plus a
+    self-loop on every vertex -- the reference's Reddit is exactly that: 114 615 892 directed entries (two per
+    undirected edge) + 232 968 self-loops = the 114 848 860 of test/test_matrix.cpp:48-58 (prep.py:113 adds the
+    loops).  Pattern A = A^T, so the forward matrix (A D^-1)^T and the backward matrix A D^-1 BOTH have
+    power-law rows AND popular columns (synth_powerlaw_csr gives each matrix only one of the two).
+      * expected degrees: the same clipped-Pareto sequence as synth_powerlaw_csr;
+      * edges: endpoints drawn in proportion to the expected degree (Chung-Lu), self-pairs and repeated pairs
+        dropped, redrawn until EXACTLY (nnz_target - n) / 2 distinct pairs exist -- a simple graph;
+      * rows hold their columns in ascending order (lower neighbours, self-loop, upper neighbours), as a
+        scipy-written graph.bin does (prep.py:46-76 writes `g.adj(scipy_fmt='csr')`); unit values.
+    Deterministic for a seed.  nnz_target - n must be even."""
+    m2 = nnz_target - n
+    if m2 < 0 or m2 % 2 or m2 // 2 > n * (n - 1) // 2:
+        raise ValueError(f"{nnz_target} non-zeros cannot be n = {n} self-loops plus both directions of a simple graph")
+    m = m2 // 2
+    rng = np.random.default_rng(seed)
+    raw = rng.pareto(alpha, size=n) + 1.0
+    w = raw
+    for _ in range(64):
+        w = np.clip(w * (m2 / max(w.sum(), 1.0)), 1.0, float(max(1, max_deg - 1)))
+        if abs(w.sum() - m2) < 0.5 * n:
+            break
+    # stub table: vertex i appears round(w_i) times; a uniform draw from it is a draw ~ expected degree
+    stubs = np.repeat(np.arange(n, dtype=np.uint32), np.maximum(1, np.rint(w)).astype(np.int64))
+    T = stubs.shape[0]
+
+    def draw(k):
+        """k vertex pairs (u < v) as keys u*n + v, endpoints ~ expected degree, self-pairs dropped"""
+        a = stubs[rng.integers(0, T, size=k)].astype(np.int64)
+        b = stubs[rng.integers(0, T, size=k)].astype(np.int64)
+        lo, hi = np.minimum(a, b), np.maximum(a, b)
+        keep = lo != hi
+        return lo[keep] * n + hi[keep]
+
+    keys = np.empty(0, dtype=np.int64)
+    while keys.shape[0] < m:
+        need = m - keys.shape[0]
+        keys = np.concatenate([keys, draw(int(need * 1.08) + 16)])
+        keys.sort()
+        first = np.ones(keys.shape[0], dtype=bool)
+        np.not_equal(keys[1:], keys[:-1], out=first[1:])
+        keys = keys[first]
+        if keys.shape[0] > m:                                   # too many: drop a random subset, keep the order
+            first = np.ones(keys.shape[0], dtype=bool)
+            first[rng.choice(keys.shape[0], size=keys.shape[0] - m, replace=False)] = False
+            keys = keys[first]
+    del stubs, first
+    u = keys // n                                               # sorted by (u, v): the upper triangle in CSR order
+    v = (keys - u * n).astype(np.int32)
+    del keys
+    up_cnt = np.bincount(u, minlength=n).astype(np.int64)       # neighbours above the diagonal, per row
+    del u
+    up_ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(up_cnt, out=up_ptr[1:])
+    # lower triangle = the transpose of the upper one: scipy's CSR -> CSC is a stable counting sort (rows ascending
+    # inside every column), O(m)
+    import scipy.sparse as sp
+    low = sp.csr_matrix((np.ones(m, dtype=np.int8), v, up_ptr), shape=(n, n)).tocsc()
+    lo_cnt = np.diff(low.indptr).astype(np.int64)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lo_cnt + 1 + up_cnt, out=indptr[1:])
+    assert indptr[-1] == nnz_target and indptr[-1] < 2 ** 32
+    indices = np.empty(nnz_target, dtype=np.uint32)
+    pos = np.arange(m, dtype=np.int64)
+    # row r = [lower neighbours | r | upper neighbours]
+    indices[pos + np.repeat(indptr[:-1] + lo_cnt + 1 - up_ptr[:-1], up_cnt)] = v
+    indices[pos + np.repeat(indptr[:-1] - low.indptr[:-1].astype(np.int64), lo_cnt)] = low.indices
+    del pos, v, low
+    indices[indptr[:-1] + lo_cnt] = np.arange(n, dtype=np.uint32)
+    return indptr.astype(np.uint32), indices, np.ones(nnz_target, dtype=np.float32)
+
+
 REDDIT_SHAPE = dict(n=232_968, nnz=114_848_860, features=608, classes=41, max_deg=21_657)
 
 
-def synth_reddit_like(scale: float = 1.0, seed: int = 1):
+def synth_reddit_like(scale: float = 1.0, seed: int = 1, symmetric: bool = False):
     """Graph + features + labels with Reddit's published shape (reference
     test/test_matrix.cpp:45-62: n=232 968, nnz=114 848 860, F=608; 41 classes), or a
-    ``scale``d-down version with the same mean degree (n multiple of 8 as prep.py:101-103)."""
+    ``scale``d-down version with the same mean degree (n multiple of 8 as prep.py:101-103).
+    ``symmetric``: pattern A = A^T like the real dataset (synth_symmetric_powerlaw_csr); the default is the
+    SURVEY.md 8(d) stand-in the headline numbers are quoted on (random columns)."""
     n = int(REDDIT_SHAPE["n"] * scale) // 8 * 8
     nnz = int(REDDIT_SHAPE["nnz"] * scale)
     mean_deg = nnz / max(n, 1)
     # keep the published maximum at full scale; scaled-down graphs keep the skew ratio
     # (max/mean ~ 44) as far as duplicates-allowed rows make sense
     max_deg = int(max(4 * mean_deg + 8, REDDIT_SHAPE["max_deg"] * min(1.0, scale * 4)))
-    indptr, indices, data = synth_powerlaw_csr(n, nnz, max_deg, seed)
+    if symmetric:
+        nnz -= (nnz - n) % 2
+        indptr, indices, data = synth_symmetric_powerlaw_csr(n, nnz, min(max_deg, n - 1), seed)
+    else:
+        indptr, indices, data = synth_powerlaw_csr(n, nnz, max_deg, seed)
     rng = np.random.default_rng(seed + 1)
     X = rng.standard_normal((n, REDDIT_SHAPE["features"]), dtype=np.float32)
     Y = rng.integers(0, REDDIT_SHAPE["classes"], size=(n, 1)).astype(np.int32)

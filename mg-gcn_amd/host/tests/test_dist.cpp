@@ -8,7 +8,8 @@
 // `gcn` of the same layer at the same padded class count (src/main.cpp:135): dist_gcn<true,...> in every
 // exchange schedule (allgather in K pieces / halo / the reference's rounds), overlap on and off (-S),
 // fused and reference launch sequences.  P = 1 must reproduce the single-GPU gradients BIT FOR BIT (same
-// kernels on the same operands); P > 1 regroups the sums (1e-4 relative).
+// kernels on the same operands); P > 1 regroups the sums: 1e-4 relative on the loss and every gradient of BOTH epochs
+// (the second epoch restarts from the single-GPU parameters, see run_dist).
 #include <cstdint>
 #include <cstdlib>
 #include <string>
@@ -55,7 +56,9 @@ static double relerr(const std::vector<float> &got, const std::vector<float> &wa
 
 struct epoch_result {
     float loss[2], acc[2];
-    std::vector<std::vector<float>> G_W, G_b, W;
+    std::vector<std::vector<float>> G_W[2], G_b[2];           // gradients of epoch 0 and of epoch 1
+    std::vector<std::vector<float>> W1, b1;                   // parameters after epoch 0's Adam step
+    std::vector<std::vector<float>> W;                        // ... and after epoch 1's
 };
 
 static epoch_result run_single(csr_matrix<x_t, v_t, r_t> A, const std::vector<std::size_t> &sizes, dn_matrix<r_t> X,
@@ -67,19 +70,27 @@ static epoch_result run_single(csr_matrix<x_t, v_t, r_t> A, const std::vector<st
         auto [loss, acc] = G.train_forward(ctx, X, Y);
         G.backward(ctx);
         ctx.sync();
-        if (e == 0)
-            for (auto &l : G.layers()) { r.G_W.push_back(l.GW().to_host()); r.G_b.push_back(l.Gb().to_host()); }
+        for (auto &l : G.layers()) { r.G_W[e].push_back(l.GW().to_host()); r.G_b[e].push_back(l.Gb().to_host()); }
         G.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8);
         ctx.sync();
         r.loss[e] = loss;
         r.acc[e] = acc;
+        if (e == 0)
+            for (auto &l : G.layers()) { r.W1.push_back(l.W().to_host()); r.b1.push_back(l.b().to_host()); }
     }
     for (auto &l : G.layers()) r.W.push_back(l.W().to_host());
     return r;
 }
 
+// Every epoch is held to the 1e-4 bar.  Epoch 0 starts from identical seed-99 parameters.  Adam's first step is
+// lr * g / (|g| + eps): where |g| is rounding noise its SIGN -- a whole 0.01 step of that weight -- differs between two
+// correct summation orders, so a free-running second epoch of a P > 1 model (regrouped sums) is not comparable at 1e-4.
+// Therefore: after epoch 0's Adam step the replicas are (1) checked against the single-GPU parameters up to such sign
+// flips (|dW| <= 2 lr), then (2) OVERWRITTEN with the single-GPU parameters, and epoch 1 -- the epoch that re-uses
+// every buffer, event and exchange slot of the multi-stream schedule -- is compared at 1e-4: loss and every G_W / G_b.
 static epoch_result run_dist(std::size_t P, csr_matrix<x_t, v_t, r_t> A0, const std::vector<std::size_t> &sizes, dn_matrix<r_t> X,
-                             dn_matrix<std::int32_t> Y, bool fused, dist_mode mode, bool overlap, std::string *transport) {
+                             dn_matrix<std::int32_t> Y, bool fused, dist_mode mode, bool overlap, std::string *transport,
+                             const epoch_result &single) {
     // the CLI's sequence, src/main.cpp:134-153
     csr_matrix<x_t, v_t, r_t> A(A0.indptr(), A0.indices(), A0.data(), A0.m());
     dist_context ctx(P, overlap);
@@ -97,48 +108,77 @@ static epoch_result run_dist(std::size_t P, csr_matrix<x_t, v_t, r_t> A0, const 
         auto [loss, acc] = G.train_forward(ctx, Xd, Yd);
         G.backward(ctx);
         ctx.sync();
-        if (e == 0)
-            for (auto &l : G.layers()) {
-                for (std::size_t j = 1; j < P; j++) {          // replicas agree bit for bit after the all-reduce
-                    ctx[j].set();
-                    CHECK(l.GW()[j].to_host() == l.GW()[0].to_host());
-                    CHECK(l.Gb()[j].to_host() == l.Gb()[0].to_host());
-                }
-                ctx[0].set();
-                r.G_W.push_back(l.GW()[0].to_host());
-                r.G_b.push_back(l.Gb()[0].to_host());
+        for (auto &l : G.layers()) {
+            for (std::size_t j = 1; j < P; j++) {          // replicas agree bit for bit after the all-reduce
+                ctx[j].set();
+                CHECK(l.GW()[j].to_host() == l.GW()[0].to_host());
+                CHECK(l.Gb()[j].to_host() == l.Gb()[0].to_host());
             }
+            ctx[0].set();
+            r.G_W[e].push_back(l.GW()[0].to_host());
+            r.G_b[e].push_back(l.Gb()[0].to_host());
+        }
         G.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8);
         ctx.sync();
         r.loss[e] = loss;
         r.acc[e] = acc;
-    }
-    for (auto &l : G.layers()) {
-        for (std::size_t j = 1; j < P; j++) { ctx[j].set(); CHECK(l.W()[j].to_host() == l.W()[0].to_host()); }
-        ctx[0].set();
-        r.W.push_back(l.W()[0].to_host());
+        std::size_t li = 0;
+        for (auto &l : G.layers()) {
+            for (std::size_t j = 1; j < P; j++) { ctx[j].set(); CHECK(l.W()[j].to_host() == l.W()[0].to_host()); }
+            ctx[0].set();
+            if (e == 0) {
+                r.W1.push_back(l.W()[0].to_host());
+                r.b1.push_back(l.b()[0].to_host());
+                for (std::size_t j = 0; j < P; j++) {      // (2) every replica continues from the single-GPU parameters
+                    ctx[j].set();
+                    auto Wj = l.W()[j], bj = l.b()[j];     // shared handles of replica j's buffers
+                    Wj.init(single.W1[li]);
+                    bj.init(single.b1[li]);
+                }
+                ctx[0].set();
+            } else {
+                r.W.push_back(l.W()[0].to_host());
+            }
+            li++;
+        }
+        ctx.sync();
     }
     mggcn_set_device(0);
     return r;
 }
 
+static double max_abs_diff(const std::vector<float> &a, const std::vector<float> &b) {
+    double m = a.size() == b.size() ? 0.0 : 1e30;
+    for (std::size_t i = 0; i < a.size() && i < b.size(); i++) m = std::max(m, std::fabs((double)a[i] - (double)b[i]));
+    return m;
+}
+
 static void compare(std::size_t P, const epoch_result &d, const epoch_result &s, double n) {
     const double tol = 1e-4;
-    CHECK(std::fabs(d.loss[0] - s.loss[0]) <= tol * std::fabs(s.loss[0]));
-    CHECK(std::fabs(d.acc[0] - s.acc[0]) <= 3.0 / n);
-    // second epoch: one Adam step apart.  Adam's first step is lr * g / (|g| + eps): where |g| is rounding noise its sign
-    // -- hence a whole 0.01 step of that weight -- differs between two correct summation orders, so P > 1 (regrouped
-    // sums) may move away from the single-GPU trajectory by a fraction of a percent; P = 1 must not.
-    CHECK(std::fabs(d.loss[1] - s.loss[1]) <= (P == 1 ? 1e-6 : 2e-2) * std::fabs(s.loss[1]));
+    for (int e = 0; e < 2; e++) {
+        CHECK(std::fabs(d.loss[e] - s.loss[e]) <= (P == 1 ? 1e-6 : tol) * std::fabs(s.loss[e]));
+        CHECK(std::fabs(d.acc[e] - s.acc[e]) <= 3.0 / n);
+        for (std::size_t l = 0; l < s.G_W[e].size(); l++) {
+            if (P == 1) {                                  // same kernels on the same operands
+                CHECK(d.G_W[e][l] == s.G_W[e][l]);
+                CHECK(d.G_b[e][l] == s.G_b[e][l]);
+            } else {
+                CHECK(relerr(d.G_W[e][l], s.G_W[e][l]) <= tol);
+                CHECK(relerr(d.G_b[e][l], s.G_b[e][l]) <= tol);
+            }
+        }
+    }
     CHECK(d.loss[1] < d.loss[0]);
-    for (std::size_t l = 0; l < s.G_W.size(); l++) {
+    for (std::size_t l = 0; l < s.W1.size(); l++) {
         if (P == 1) {
-            CHECK(d.G_W[l] == s.G_W[l]);
-            CHECK(d.G_b[l] == s.G_b[l]);
+            CHECK(d.W1[l] == s.W1[l]);
             CHECK(d.W[l] == s.W[l]);
         } else {
-            CHECK(relerr(d.G_W[l], s.G_W[l]) <= tol);
-            CHECK(relerr(d.G_b[l], s.G_b[l]) <= tol);
+            // (1) the replicas' own Adam step: equal up to sign flips of rounding-noise gradients (2 lr = 0.02)
+            CHECK(max_abs_diff(d.W1[l], s.W1[l]) <= 2.05e-2);
+            CHECK(max_abs_diff(d.b1[l], s.b1[l]) <= 2.05e-2);
+            // second Adam step from the same parameters and (nearly) the same moments
+            CHECK(max_abs_diff(d.W[l], s.W[l]) <= 2.05e-2);
         }
     }
 }
@@ -167,7 +207,7 @@ int main(int argc, char **argv) {
             for (const bool overlap : {true, false}) {
                 const int before = g_failures;
                 std::string transport;
-                const auto dist = run_dist(P, A, sizes, X, Y, fused, mode, overlap, &transport);
+                const auto dist = run_dist(P, A, sizes, X, Y, fused, mode, overlap, &transport, single);
                 compare(P, dist, single, (double)n);
                 const char *mn = mode == dist_mode::allgather ? "allgather" : mode == dist_mode::halo ? "halo" : "rounds";
                 std::printf("%s: dist_gcn P=%zu %s overlap=%d fused=%d transport=%s  loss %.7f -> %.7f (single GPU %.7f -> %.7f)\n",

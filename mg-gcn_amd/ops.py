@@ -35,6 +35,13 @@ class spmm_buffer:
     def num_launches(self, d: int) -> int: return self.lib.mggcn_spmm_plan_num_launches(self.handle, int(d))
     def nbytes(self) -> int: return self.lib.mggcn_spmm_plan_bytes(self.handle)
 
+    def describe(self) -> str:
+        """what the plan builder measured and decided (mggcn_spmm_plan_describe)"""
+        import ctypes
+        buf = ctypes.create_string_buffer(4096)
+        self.lib.mggcn_spmm_plan_describe(self.handle, buf, 4096)
+        return buf.value.decode()
+
     def __del__(self):
         try:
             if self.handle:

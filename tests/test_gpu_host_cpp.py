@@ -49,10 +49,9 @@ def test_cli_matches_oracle(pkg, oracle, tmp_path, fused):
         want.append(O.train_forward(X, Y)); O.backward(); O.adam_update()
     assert [int(g[0]) for g in got] == [0, 1, 2]
     assert abs(got[0][1] - want[0][0]) <= 1e-4 * want[0][0]            # identical inputs at epoch 0
-    for g, w in zip(got, want):
-        assert abs(g[1] - w[0]) <= 2e-3 * w[0] and abs(g[2] - w[1]) <= 0.02    # free-running: Adam's lr*g/|g| drift, see test_gpu_gcn
-    # ... and every epoch at the 1e-4 bar from the exact state the CLI started it in (weights dumped by
-    # MGGCN_DUMP_WEIGHTS): the drift above is the optimiser's conditioning, not the kernels
+    # every epoch at the 1e-4 bar from the exact state the CLI started it in (weights dumped by MGGCN_DUMP_WEIGHTS;
+    # free-running trajectories are not comparable at 1e-4: Adam's lr * g / |g| turns the sign of a rounding-noise
+    # gradient into a whole 0.01 step -- the optimiser's conditioning, not the kernels)
     O2 = oracle.Gcn(oracle.Csr(ip, ix, dv, n), [F, 16, 16, C])
     for e in range(3):
         for li, layer in enumerate(O2.layers):

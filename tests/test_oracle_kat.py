@@ -29,17 +29,24 @@ LOGITS = np.array([[2, 1, 2], [4, 2, 1], [1, -1, 0]], dtype=np.float32)
 Y3 = np.array([0, 0, 1], dtype=np.int32)
 
 
-def test_cross_entropy_kat(oracle):
-    ls, ac, G, _ = oracle.softmax_cross_entropy(LOGITS.copy(), Y3)
+# f64acc: the exact-accumulation twin (every SpMM / GEMM / softmax row sum in fp64, rounded once) that judges the
+# full-size configs (tests/test_gpu_configs.py) is held to the SAME reference vectors as the fp32 restatement
+F64 = pytest.mark.parametrize("f64acc", [False, True], ids=["f32", "f64acc"])
+
+
+@F64
+def test_cross_entropy_kat(oracle, f64acc):
+    ls, ac, G, _ = oracle.softmax_cross_entropy(LOGITS.copy(), Y3, f64acc=f64acc)
     close(ls / 3, 1.146482)
     close(G.reshape(-1), [-0.1925604, 0.0517875, 0.1407729, -0.0520684, 0.0380651, 0.0140034,
                           0.2217470, -0.3033231, 0.0815762])
     assert ac == 2.0        # rows 0 (tie -> first max) and 1 are predicted as class 0
 
 
-def test_leaky_relu_kat(oracle):
+@F64
+def test_leaky_relu_kat(oracle, f64acc):
     H = oracle.leaky_relu_forward(LOGITS)
-    ls, _, G, _ = oracle.softmax_cross_entropy(H, Y3)
+    ls, _, G, _ = oracle.softmax_cross_entropy(H, Y3, f64acc=f64acc)
     # the reference passes the PRE-activation logits as `in` here (test_gcn.cpp:133)
     G = oracle.leaky_relu_backward(LOGITS, G)
     close(ls / 3, 0.8637248)
@@ -57,17 +64,17 @@ EXP_GW = [-1.9377153, 1.9377153, -0.9866424, 0.9866424, -0.4873929, 0.4873929]
 EXP_GOUT = [0.4873929, 0.4873929, 0.4873930, -0.0118565, -0.0118565, -0.0118565]
 
 
-def _chain(oracle, a_mul, at_mul):
-    XW = oracle.gemm(X23, W32)
+def _chain(oracle, a_mul, at_mul, f64acc=False):
+    XW = oracle.gemm(X23, W32, f64acc=f64acc)
     AXW = np.repeat(B12, 2, axis=0).copy()                   # broadcast_rows(b, AXW)
     AXW = a_mul(XW, AXW)                                     # AXW = A.XW + AXW  (beta = 1)
     H = oracle.leaky_relu_forward(AXW)
-    ls, _, G, _ = oracle.softmax_cross_entropy(H, Y2)
+    ls, _, G, _ = oracle.softmax_cross_entropy(H, Y2, f64acc=f64acc)
     G = oracle.leaky_relu_backward(AXW, G)
-    G_b = oracle.gemm(np.ones((1, 2), dtype=np.float32), G)
+    G_b = oracle.gemm(np.ones((1, 2), dtype=np.float32), G, f64acc=f64acc)
     G_XW = at_mul(G)
-    G_W = oracle.gemm(X23, G_XW, A_T=True)
-    G_out = oracle.gemm(G_XW, W32, B_T=True)
+    G_W = oracle.gemm(X23, G_XW, A_T=True, f64acc=f64acc)
+    G_out = oracle.gemm(G_XW, W32, B_T=True, f64acc=f64acc)
     return ls / 2, G, G_b, G_W, G_out
 
 
@@ -80,17 +87,81 @@ def _check_chain(res):
     close(G_out.reshape(-1), EXP_GOUT)
 
 
-def test_g_dense_kat(oracle):
+@F64
+def test_g_dense_kat(oracle, f64acc):
     A = np.array([[1, 0], [0.5, 0.5]], dtype=np.float32)
-    _check_chain(_chain(oracle, lambda XW, C: oracle.gemm(A, XW, C, 1.0, 1.0),
-                        lambda G: oracle.gemm(A, G, A_T=True)))
+    _check_chain(_chain(oracle, lambda XW, C: oracle.gemm(A, XW, C, 1.0, 1.0, f64acc=f64acc),
+                        lambda G: oracle.gemm(A, G, A_T=True, f64acc=f64acc), f64acc))
 
 
-def test_csr_g_kat(oracle):
+@F64
+def test_csr_g_kat(oracle, f64acc):
     A = oracle.Csr([0, 1, 3], [0, 0, 1], [1, 0.5, 0.5], 2)
     At = oracle.transpose(A)
-    _check_chain(_chain(oracle, lambda XW, C: oracle.spmm(A, XW, C, 1.0, 1.0),
-                        lambda G: oracle.spmm(At, G)))
+    _check_chain(_chain(oracle, lambda XW, C: oracle.spmm(A, XW, C, 1.0, 1.0, f64acc=f64acc),
+                        lambda G: oracle.spmm(At, G, f64acc=f64acc), f64acc))
+
+
+@F64
+def test_csr_g_kat_through_the_layer_classes(oracle, f64acc):
+    """The same reference vectors (test/test_gcn.cpp:231-246) through the classes the full-size judge is made of --
+    oracle.GcnLayer / Linear / Gcn's loss call with ``f64acc`` threaded through.  The KAT adds the bias AFTER the
+    aggregation and takes G_b before A^T; the layer adds it before and sums after: identical because the KAT's A is
+    row-stochastic (A 1 = 1, hence A (XW + 1 b^T) = A XW + 1 b^T and 1^T A^T G = 1^T G)."""
+    A = oracle.Csr([0, 1, 3], [0, 0, 1], [1, 0.5, 0.5], 2)
+    At = oracle.transpose(A)
+    layer = oracle.GcnLayer(lambda B: oracle.spmm(A, B, f64acc=f64acc), lambda B: oracle.spmm(At, B, f64acc=f64acc),
+                            3, 2, True, True, f64acc)
+    layer.lin.W, layer.lin.b = W32.copy(), B12.copy()
+    Z = layer.forward(X23)
+    ls, _, G, _ = oracle.softmax_cross_entropy(Z, Y2, f64acc=f64acc)
+    G_out = layer.backward(G)
+    close(ls / 2, 3.2750449)
+    close(layer.lin.G_b.reshape(-1), EXP_GB)
+    close(layer.lin.G_W.reshape(-1), EXP_GW)
+    close(G_out.reshape(-1), EXP_GOUT)
+
+
+def test_gemm_f64acc_against_numpy_fp64(oracle):
+    """orc_gemm_f64acc (the twin's GEMM): every transpose combination, alpha / beta, long K -- against NumPy fp64
+    rounded once; and the fp32 restatement's distance to it grows with K while the twin's does not."""
+    rng = np.random.default_rng(11)
+    for (M, N, K) in [(9, 5, 7), (3, 41, 128), (2, 3, 200_000)]:
+        for A_T in (False, True):
+            for B_T in (False, True):
+                A = rng.standard_normal((K, M) if A_T else (M, K)).astype(np.float32)
+                B = rng.standard_normal((N, K) if B_T else (K, N)).astype(np.float32)
+                C0 = rng.standard_normal((M, N)).astype(np.float32)
+                want = 0.5 * ((A.T if A_T else A).astype(np.float64) @ (B.T if B_T else B).astype(np.float64)) + 2.0 * C0
+                got = oracle.gemm(A, B, C0.copy(), 0.5, 2.0, A_T=A_T, B_T=B_T, f64acc=True)
+                np.testing.assert_allclose(got, want.astype(np.float32), rtol=3e-7, atol=1e-6 * np.abs(want).max())
+    ones = np.ones((1, 200_000), dtype=np.float32)
+    g = (rng.standard_normal((200_000, 4)) * 1e-3 + 1e-3).astype(np.float32)
+    exact = g.astype(np.float64).sum(axis=0)
+    e64 = np.abs(oracle.gemm(ones, g, f64acc=True) - exact).max() / np.abs(exact).max()
+    e32 = np.abs(oracle.gemm(ones, g) - exact).max() / np.abs(exact).max()
+    assert e64 <= 1e-7 and e64 <= e32
+
+
+def test_gcn_f64acc_twin_stays_within_fp32_rounding_of_the_restatement(oracle):
+    """Gcn(f64acc=True) against Gcn() on a graph small enough that fp32 summation order cannot matter: the twin is
+    the same algorithm (loss, every gradient equal to a few ulps), not a different model."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    n = 96
+    M = sp.csr_matrix(sp.random(n, n, density=0.1, format="csr", dtype=np.float32, random_state=3) + sp.eye(n, dtype=np.float32, format="csr"))
+    X = rng.standard_normal((n, 10)).astype(np.float32)
+    Y = rng.integers(0, 4, size=(n, 1)).astype(np.int32)
+    out = []
+    for f64 in (False, True):
+        O = oracle.Gcn(oracle.Csr(M.indptr, M.indices, M.data, n), [10, 12, 8, 4], f64acc=f64)
+        loss, acc = O.train_forward(X, Y)
+        O.backward()
+        out.append((loss, acc, [(l.lin.G_W.copy(), l.lin.G_b.copy()) for l in O.layers]))
+    assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[1][0]) and out[0][1] == out[1][1]
+    for (gw0, gb0), (gw1, gb1) in zip(out[0][2], out[1][2]):
+        assert np.abs(gw0 - gw1).max() <= 5e-6 * np.abs(gw1).max()
+        assert np.abs(gb0 - gb1).max() <= 5e-6 * np.abs(gb1).max()
 
 
 def _load(pkg, golden_dir, name):
