@@ -56,6 +56,10 @@ void mggcn_comm_allgather_f32(mggcn_comm *comm, const float *const *send, float 
  * send[j] holds rank j's outgoing pieces in destination order, recv[k] receives in source order. */
 void mggcn_comm_alltoallv_f32(mggcn_comm *comm, const float *const *send, float *const *recv,
                               const size_t *counts, const mggcn_stream_t *streams);
+/* The displacement tables mggcn_comm_alltoallv_f32 derives from `counts` (host arithmetic only, no GPU; exported so
+ * that a CPU test can pin them): sdis[j*P + k] = offset in send[j] of the piece for GPU k, rdis[j*P + k] = offset in
+ * recv[j] of the piece from GPU k.  All three arrays hold P*P entries. */
+void mggcn_comm_alltoallv_displacements(int P, const size_t *counts, size_t *sdis, size_t *rdis);
 /* bufs[j] <- sum_i bufs[i], in place, on every GPU j. */
 void mggcn_comm_allreduce_sum_f32(mggcn_comm *comm, float *const *bufs, size_t count,
                                   const mggcn_stream_t *streams);

@@ -21,6 +21,7 @@
 #include <set>
 #include <vector>
 
+#include "comm_layout.h"
 #include "mggcn_comm.h"
 
 #define MGGCN_API extern "C" __attribute__((visibility("default")))
@@ -187,16 +188,15 @@ MGGCN_API void mggcn_comm_allgather_f32(mggcn_comm *comm, const float *const *se
     CHECK_RCCL(ncclGroupEnd());
 }
 
+MGGCN_API void mggcn_comm_alltoallv_displacements(int P, const size_t *counts, size_t *sdis, size_t *rdis) {
+    mggcn_layout::alltoallv_displacements(P, counts, sdis, rdis);
+}
+
 MGGCN_API void mggcn_comm_alltoallv_f32(mggcn_comm *comm, const float *const *send, float *const *recv,
                                         const size_t *counts, const mggcn_stream_t *streams) {
-    // counts[j * P + k] floats go from rank j to rank k; both sides keep their pieces in rank order
     const int P = (int)comm->devices.size();
     std::vector<size_t> sdis((size_t)P * P, 0), rdis((size_t)P * P, 0);
-    for (int j = 0; j < P; j++)
-        for (int k = 1; k < P; k++) {
-            sdis[(size_t)j * P + k] = sdis[(size_t)j * P + k - 1] + counts[(size_t)j * P + k - 1];
-            rdis[(size_t)j * P + k] = rdis[(size_t)j * P + k - 1] + counts[(size_t)(k - 1) * P + j];   // rank j receives from k-1
-        }
+    mggcn_comm_alltoallv_displacements(P, counts, sdis.data(), rdis.data());
     if (comm->p2p) {
         p2p_exchange(comm, streams, [&](int k) {
             for (int j = 0; j < P; j++)

@@ -505,7 +505,11 @@ def load_rank_local_host(dctx: host_comm, dirname: str):
     same would hold P whole copies of A, A^T and all P x P blocks on one host -- papers100M: 8 x 40 GB):
       * rows p[r]..p[r+1] of graph.bin / features.bin / labels.bin through the indptr offsets (datasets.read_csr_rows),
       * column sums of A by ONE all-reduce of the per-rank partial sums (fp64) -> this rank's rows of the
-        column-normalised A D^-1 (csr_matrix::normalize(true), src/matrix.hpp:340-364),
+        column-normalised A D^-1 (csr_matrix::normalize(true), src/matrix.hpp:340-364).  Exactness: with the unit
+        (integer) edge weights the reference's data-prep writes (test/data/prep.py:113) the sums are exact in any
+        order and the result is BITWISE the whole-graph path's (asserted in tests/test_dist_cpu.py); with
+        non-unit weights the reference and mggcn_csr_normalize_host add in fp32 in row order while these partial
+        sums are fp64, so values may differ from the P = 1 matrix in the last ulp (parity unpinned there),
       * this rank's rows of (A D^-1)^T by ONE all-to-all: every entry (i, c) goes to the owner of column c, which
         receives its transposed rows already in increasing source-row order (src/matrix.hpp:392-424),
       * the class count 1 + max(Y) by a max all-reduce (src/main.cpp:89).

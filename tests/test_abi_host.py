@@ -306,7 +306,7 @@ def test_comm_library_exports_every_declared_symbol():
     text = open(os.path.join(ROOT, "include", "mggcn_comm.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = sorted(set(re.findall(r"\b(mggcn_comm_[a-z0-9_]+)\s*\(", text)))
-    assert len(names) == 8, names
+    assert len(names) == 9, names
     lib = os.path.join(ROOT, "mg-gcn_amd", "lib", "libmggcn_comm.so")
     assert os.path.exists(lib), "build() must produce libmggcn_comm.so"
     nm = None
@@ -318,6 +318,44 @@ def test_comm_library_exports_every_declared_symbol():
     assert nm is not None, "no nm tool"
     exported = set(re.findall(r"\b(mggcn_comm_[a-z0-9_]+)\b", nm))
     assert not [n for n in names if n not in exported], (names, sorted(exported))
+
+
+def test_alltoallv_displacements_against_a_simulated_exchange(tmp_path):
+    """csrc/comm_layout.h (the send / receive offsets both transports of mggcn_comm_alltoallv_f32 use; ADVICE r02: the
+    RCCL branch has never run on more than one GPU): compiled on the host and checked against a numpy simulation of
+    the exchange -- every rank packs its outgoing pieces in destination order, every receiver must find the piece
+    of source k exactly where rdis says, in source order, with nothing overlapping and nothing left over."""
+    src = tmp_path / "disp.cpp"
+    src.write_text(
+        '#include <cstdio>\n#include <cstdlib>\n#include <vector>\n#include "comm_layout.h"\n'
+        'int main(int argc, char **argv) { int P = std::atoi(argv[1]); std::vector<std::size_t> c(P * P), s(P * P), r(P * P);\n'
+        '  for (int i = 0; i < P * P; i++) c[i] = std::strtoull(argv[2 + i], nullptr, 10);\n'
+        '  mggcn_layout::alltoallv_displacements(P, c.data(), s.data(), r.data());\n'
+        '  for (auto x : s) std::printf("%zu ", x); std::printf("\\n"); for (auto x : r) std::printf("%zu ", x); std::printf("\\n"); }\n')
+    exe = tmp_path / "disp"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "mg-gcn_amd", "csrc"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(0)
+    for P in (1, 2, 3, 8):
+        counts = rng.integers(0, 7, size=(P, P))
+        counts[rng.integers(0, P), :] = 0                      # a rank that sends nothing
+        out = subprocess.run([str(exe), str(P)] + [str(int(x)) for x in counts.reshape(-1)], capture_output=True, text=True)
+        assert out.returncode == 0
+        sdis, rdis = (np.array(ln.split(), dtype=np.int64).reshape(P, P) for ln in out.stdout.strip().splitlines())
+        # simulate: send[j] = pieces for k = 0..P-1 back to back, each element tagged (source, destination, index)
+        send = [[(j, k, e) for k in range(P) for e in range(counts[j, k])] for j in range(P)]
+        recv = [[None] * int(counts[:, k].sum()) for k in range(P)]
+        for j in range(P):
+            for k in range(P):
+                piece = send[j][sdis[j, k]:sdis[j, k] + counts[j, k]]
+                assert all(t[:2] == (j, k) for t in piece)
+                for e, t in enumerate(piece):
+                    assert recv[k][rdis[k, j] + e] is None     # no overlap
+                    recv[k][rdis[k, j] + e] = t
+        for k in range(P):
+            assert all(t is not None for t in recv[k])         # nothing left over
+            assert [t[0] for t in recv[k]] == sorted(t[0] for t in recv[k])      # source order
 
 
 def test_public_headers_are_plain_c(tmp_path):
