@@ -46,6 +46,51 @@ def spmm_bytes_gather(n_rows, nnz, d):
     return 4 * (n_rows + 1) + 8 * nnz + 4 * nnz * d + 4 * n_rows * d
 
 
+def spmm_kernel_sha():
+    """content hash of the SpMM kernel sources: profiles/spmm_hbm_traffic.json carries the hash its counters were
+    collected with, so a stale `traffic` figure is visible in the line (and fails tests/test_abi_host.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("spmm.hip", "spmm_sweep.hip", "spmm_internal.h"):
+        with open(os.path.join(ROOT, "mg-gcn_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def run_cli_epochs(pkg, indptr, indices, data, X, Y, hidden, epochs=8):
+    """`mg_gcn -E <epochs> train <dir> <k> <h...>` (the reference's interface, src/main.cpp:113-131) on the same
+    workload, written in the reference's on-disk format: median of the CLI's OWN per-epoch seconds (epochs 2..),
+    and its set-up (process start to the end of epoch 0 minus one epoch: file load, normalise / transpose, plans)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "mg-gcn_amd", "bin", "mg_gcn")
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="mggcn_bench_cli_")
+    try:
+        d = os.path.join(tmp, "permuted", "bench")
+        pkg.datasets.write_dataset(d, indptr, indices, data, X, Y)
+        t = time.perf_counter()
+        r = subprocess.run([exe, "-E", str(epochs), "train", d, str(len(hidden))] + [str(h) for h in hidden],
+                           cwd=tmp, capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t
+        if r.returncode != 0:
+            return {"error": r.stderr[-300:]}
+        ep = []
+        for ln in r.stderr.splitlines():
+            t4 = ln.split()
+            if len(t4) == 4 and t4[0].isdigit():
+                ep.append((float(t4[1]), float(t4[3])))
+        if len(ep) < 3:
+            return {"error": "no epoch lines"}
+        med = float(np.median([e[1] for e in ep[2:]]))
+        return {"cli_epoch_ms": round(med * 1e3, 4), "cli_setup_s": round(wall - sum(e[1] for e in ep[1:]) - med, 2),
+                "cli_loss_first": ep[0][0], "cli_epochs": len(ep)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +102,14 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="the reference's -S flag")
     ap.add_argument("--unfused", action="store_true", help="reference launch sequence, no fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra keys (symmetric stand-in epoch, the mg_gcn CLI's own epoch time); never the headline")
+    ap.add_argument("--workload", default="reddit_like", choices=["reddit_like", "products_like"],
+                    help="reddit_like = BASELINE.json's headline config (default); products_like = configs[3]'s graph shape "
+                         "(n = 2 449 032, 126.2 M non-zeros, F = 128, 47 classes) -- manual mode, B >> Infinity Cache: "
+                         "the SpMM is HBM-bound there")
+    ap.add_argument("--symmetric", action="store_true",
+                    help="HEADLINE workload = the symmetric stand-in (pattern A = A^T like the real Reddit); manual mode")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
@@ -95,8 +148,14 @@ def main():
     # ---- workload ------------------------------------------------------------------
     t_gen = time.time()
     fused = not args.unfused
+
+    def make_workload(symmetric):
+        if args.workload == "products_like":
+            return pkg.datasets.synth_products_like(args.scale, seed=5, symmetric=True)      # OGB's graph is undirected
+        return pkg.datasets.synth_reddit_like(args.scale, seed=1, symmetric=symmetric)
+    wl_name = {"reddit_like": "reddit_like_3x128_gcn", "products_like": "products_like_3x128_gcn"}[args.workload]
     if P == 1:
-        (indptr, indices, data), X, Y = pkg.datasets.synth_reddit_like(args.scale, seed=1)
+        (indptr, indices, data), X, Y = make_workload(args.symmetric)
         n, nnz = int(indptr.shape[0] - 1), int(indptr[-1])
         num_labels = 1 + int(Y.max())
         sizes = [X.shape[1]] + list(args.hidden) + [num_labels]
@@ -121,9 +180,9 @@ def main():
         D = pkg.dist
         dctx = D.dist_context(overlap=not args.no_overlap, device_index=local_rank)
         ctx = dctx.ctx
-        tmp = os.path.join(tempfile.gettempdir(), f"mggcn_bench_{os.environ.get('MASTER_PORT', '0')}_{args.scale}")
+        tmp = os.path.join(tempfile.gettempdir(), f"mggcn_bench_{args.workload}_{os.environ.get('MASTER_PORT', '0')}_{args.scale}")
         if rank == 0:
-            (indptr, indices, data), X, Y = pkg.datasets.synth_reddit_like(args.scale, seed=1)
+            (indptr, indices, data), X, Y = make_workload(args.symmetric)
             pkg.datasets.write_dataset(tmp, indptr, indices, data, X, Y)
             del indptr, indices, data, X, Y
         dist.barrier()
@@ -188,13 +247,14 @@ def main():
         nr, nc, nz = spmm_shape
         b_alg = spmm_bytes_alg(nr, nc, nz, d)
         ach = b_alg / (avg * 1e-3) / 1e9
-        traffic, src = None, None
+        traffic, src, sha_ok = None, None, None
         tf = os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")     # written from separate --pmc passes
-        if P == 1 and os.path.exists(tf):
+        if P == 1 and os.path.exists(tf) and args.workload == "reddit_like" and args.scale == 1.0:   # counters of THAT shape
             try:
                 j = json.load(open(tf))
                 traffic = j.get(traffic_key, j.get("bytes_per_launch") if traffic_key == "bytes_per_call" else None)
                 src = j.get("source")
+                sha_ok = j.get("kernel_source_sha") == spmm_kernel_sha()
             except Exception:
                 traffic = None
         return {"bound": "hbm", "kernel": f"spmm_csr_f32 d={d}", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
@@ -203,6 +263,7 @@ def main():
                 # HBM-side bytes per CALL from rocprofv3 --pmc passes of an earlier run of the same kernels (this run
                 # measures time only): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 summed over the call's launches
                 "traffic": traffic, "traffic_source": src,
+                "traffic_kernel_source_current": sha_ok,      # counters collected with the kernel sources of this tree?
                 "ms_per_call": round(avg, 4), "ms_per_call_median": round(med, 4), "ms_per_call_min": round(mn, 4),
                 "kernel_launches_per_call": launches_per_call, "calls_timed": int(a.size), "bytes_alg": b_alg,
                 # what actually bounds the kernel: every gathered row crosses the L2 -> vector-L1 fill
@@ -226,11 +287,12 @@ def main():
         return round(float(np.mean(per)), 2) if per else None
 
     out = {
-        "metric": "epoch_ms (Reddit-shaped 3x128 GCN, full-graph, fp32)",
+        "metric": "epoch_ms (Reddit-shaped 3x128 GCN, full-graph, fp32)" if args.workload == "reddit_like"
+                  else "epoch_ms (ogbn-products-shaped 3x128 GCN, full-graph, fp32; manual mode)",
         "value": round(ms, 4), "unit": "ms", "n_gpus": P, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "reddit_like_3x128_gcn" if args.scale == 1.0 else f"reddit_like_scale_{args.scale}",
+        "config": {"workload": (wl_name if args.scale == 1.0 else f"{args.workload}_scale_{args.scale}") + ("_symmetric" if args.symmetric else ""),
                    "n": n, "nnz": nnz, "sizes": sizes, "spmm_per_epoch": 2 * nl - 1,
                    "parallelism": f"rows{P}" + ("" if P == 1 else f"-{args.mode}"), "fused": fused},
         "roofline": spmm_roofline(spmm_ms, d_main, launches(d_main), "bytes_per_call"),
@@ -239,8 +301,38 @@ def main():
         "setup_s": round(t_gen, 1),
     }
 
+    if P > 1:
+        out["comm"] = comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers, args)
+    if rank == 0 and P == 1 and not args.no_extras:
+        # (1) the reference's own interface on the same workload: never the headline (it synchronises inside the loss
+        #     like the reference, src/gcn.hpp:816; `value` goes through gcn.train_step with one sync per epoch)
+        cli = run_cli_epochs(pkg, indptr, indices, data, X, Y, args.hidden)
+        if cli:
+            out.update(cli)
+        # (2) the stand-in with the real dataset's STRUCTURE (A = A^T: both matrices have power-law rows and popular
+        #     columns, rows sorted): same model, same kernels, extra key only -- SURVEY.md 8(d) defined the headline graph
+        if not args.symmetric and args.workload == "reddit_like":
+            G = A = None                          # release the headline model's plans and buffers
+            torch.cuda.empty_cache()
+            t_sym = time.time()
+            (ip2, ix2, dv2), X2, Y2 = pkg.datasets.synth_reddit_like(args.scale, seed=1, symmetric=True)
+            G2 = pkg.gcn(pkg.csr_matrix(ip2, ix2, dv2, int(ip2.shape[0] - 1)), [X2.shape[1]] + list(args.hidden) + [1 + int(Y2.max())], fused=fused)
+            X2d, Y2d = pkg.dn_matrix.from_numpy(X2), pkg.dn_matrix.from_numpy(Y2)
+            for _ in range(args.warmup):
+                G2.train_step(ctx, X2d, Y2d, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            per2 = []
+            for _ in range(args.steps):
+                G2.train_step(ctx, X2d, Y2d, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+                per2.append([ctx.measure(t) for t in spmm_timers])
+            torch.cuda.synchronize()
+            out["symmetric_epoch_ms"] = round((time.perf_counter() - t2) * 1e3 / max(args.steps, 1), 4)
+            out["symmetric_spmm_ms_per_call"] = round(float(np.mean(per2)), 4) if per2 and per2[0] else None
+            out["symmetric_setup_s"] = round(time.time() - t_sym - (time.perf_counter() - t2), 1)
+            del G2, X2d, Y2d, ip2, ix2, dv2, X2, Y2
     if rank == 0 and P == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d_main)
+        out["cpu_baseline"] = cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d_main, args.workload)
         if args.warmup + args.steps > 0 and "loss" in out["cpu_baseline"]:
             out["cpu_baseline"]["loss_matches_gpu_first"] = bool(
                 abs(out["cpu_baseline"]["loss"] - losses[0]) <= 1e-4 * abs(out["cpu_baseline"]["loss"]))
@@ -253,7 +345,46 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
-def cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d):
+def comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers, args):
+    """N > 1: what the run exchanged over -- backend, communicator size, every rank's device, the RCCL version -- and
+    one SEPARATE pass of 3 epochs (after the timed ones) with the exchange events on: per d-wide SpMM the comm-stream
+    time of its collectives (`exchange_ms`), the time the compute stream stalled waiting for pieces (`exposed_ms`)
+    and overlap_frac = 1 - exposed / exchange.  Reference events: src/cuda_utils.hpp:61-89."""
+    prop = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": dctx.rank, "device": local_rank, "name": prop.name,
+          "pci_bus_id": getattr(prop, "pci_bus_id", None), "uuid": str(getattr(prop, "uuid", ""))[:13]}
+    devices = [None] * dctx.P
+    dist.all_gather_object(devices, me)
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    rep = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": devices, "rccl_version": ver,
+           "mode": args.mode, "overlap": not args.no_overlap, "rehearsal_gloo_on_one_gpu": bool(rehearsal)}
+    dctx.profile_exchange = True
+    ex, wt = [], []
+    for it in range(3):
+        epoch()
+        if it == 0:
+            continue                                              # first pass creates the events
+        for t in spmm_timers:                                     # "<layer>_<0|1>_matmul-spmm"
+            base = t[: -len("matmul-spmm")]
+            names = [k for k in dctx.ctx.timers if k.startswith(base)]
+            ex.append(sum(dctx.measure(k) for k in names if k.endswith("matmul-exchange")))
+            wt.append(sum(dctx.measure(k) for k in names if k.endswith("matmul-bcast-wait")))
+    dctx.profile_exchange = False
+    if ex:
+        e, w = float(np.mean(ex)), float(np.mean(wt))
+        both = torch.tensor([e, w], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        e, w = float(both[0]), float(both[1])
+        rep.update({"exchange_ms": round(e, 4), "exposed_ms": round(w, 4),
+                    "overlap_frac": round(1.0 - w / e, 4) if e > 0 else None,
+                    "exchange_note": "per d-wide SpMM, max over ranks, separate pass after the timed epochs"})
+    return rep
+
+
+def cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d, workload="reddit_like"):
     """The oracle (CPU restatement, kind "port") on this box's host cores, bounded to
     roughly 10-30 s: one d-wide forward SpMM on the full graph, then -- if the projected
     time allows -- one full training epoch; otherwise an epoch on a row-scaled graph."""
@@ -298,7 +429,8 @@ def cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d):
         res["sample"] = "1 full epoch of the same workload (oracle.Gcn, fp32, OpenMP)"
     else:
         frac = max(0.02, 20.0 / projected)
-        (ip, ix, dv), Xs, Ys = pkg.datasets.synth_reddit_like(frac, seed=1)
+        gen = pkg.datasets.synth_products_like if workload == "products_like" else pkg.datasets.synth_reddit_like
+        (ip, ix, dv), Xs, Ys = gen(frac)
         O = orc.Gcn(orc.Csr(ip, ix, dv, ip.shape[0] - 1), sizes)
         t = time.perf_counter()
         O.train_forward(Xs, Ys); O.backward(); O.adam_update()

@@ -59,6 +59,10 @@ void mggcn_device_synchronize(void);
  * (its compute stream). */
 mggcn_stream_t mggcn_stream_create(int high_priority);
 void mggcn_stream_destroy(mggcn_stream_t stream);
+/* Frees the small per-(device, stream) reduction scratch that mggcn_abssum_f32 / the fused loss allocate on first use
+ * (synchronises that stream).  mggcn_stream_destroy calls it; a host layer that brings its own streams (e.g. torch's)
+ * calls it when it drops one. */
+void mggcn_stream_release_scratch(mggcn_stream_t stream);
 void mggcn_stream_synchronize(mggcn_stream_t stream);
 /* event_create / context::record / context::wait / context::measure
  * (src/matrix.hpp:62-67, :107-117, :138-144) */

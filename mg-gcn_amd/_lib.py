@@ -31,6 +31,7 @@ PROTOTYPES = {
     "mggcn_device_synchronize": (None, []),
     "mggcn_stream_create": (vp, [c_int]),
     "mggcn_stream_destroy": (None, [vp]),
+    "mggcn_stream_release_scratch": (None, [vp]),
     "mggcn_stream_synchronize": (None, [vp]),
     "mggcn_event_create": (vp, []),
     "mggcn_event_destroy": (None, [vp]),

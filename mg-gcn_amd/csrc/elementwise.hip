@@ -269,13 +269,14 @@ __global__ __launch_bounds__(256) void abssum_final_kernel(const float *__restri
 // launch path: the host layers call abssum once during warm-up).  Per STREAM, not per device: several
 // contexts may drive one GPU at once (a dist_context whose ranks share a device, two models on two
 // streams) and two sums in flight on different streams must not share their partials.
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, float *> g_scratch;
+
 float *abssum_scratch(hipStream_t st) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, float *> scratch;
     int dev = 0;
     MGGCN_CHECK_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    float *&p = scratch[{dev, st}];
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    float *&p = g_scratch[{dev, st}];
     if (!p) MGGCN_CHECK_HIP(hipMalloc(&p, kScratchFloats * sizeof(float)));
     return p;
 }
@@ -658,6 +659,26 @@ MGGCN_API void mggcn_axpy_f32(mggcn_stream_t stream, const float *A, float *B, f
 
 MGGCN_API void mggcn_scale_mat_f32(mggcn_stream_t stream, float *mat, float scalar, size_t size) {
     launch_map1(as_stream(stream), mat, mat, size, Scal{scalar});
+}
+
+// The reduction scratch above belongs to a (device, stream) pair: mggcn_stream_destroy releases it with the stream;
+// a host layer whose streams come from elsewhere (torch) calls this when it drops a stream, so that a recycled
+// stream handle never inherits a buffer another stream may still be using, and nothing accumulates.
+MGGCN_API void mggcn_stream_release_scratch(mggcn_stream_t stream) {
+    int dev = 0;
+    MGGCN_CHECK_HIP(hipGetDevice(&dev));
+    float *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        auto it = g_scratch.find({dev, as_stream(stream)});
+        if (it == g_scratch.end()) return;
+        p = it->second;
+        g_scratch.erase(it);
+    }
+    if (p) {
+        MGGCN_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));      // nobody may still be summing into it
+        MGGCN_CHECK_HIP(hipFree(p));
+    }
 }
 
 MGGCN_API void mggcn_abssum_f32(mggcn_stream_t stream, const float *A, size_t size, float *result_device) {

@@ -694,8 +694,11 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
                       "split-K GEMM needs the workspace reported by mggcn_gemm_[tn_colsum_]workspace_bytes");
         slab = static_cast<float *>(workspace);
     }
-    const bool a_vec = aligned16(A) && lda % 4 == 0;
-    const bool b_vec = aligned16(B) && ldb % 4 == 0;
+    // 16-byte loads only when the operand's contiguous extent is itself a multiple of 4: with ld % 4 == 0 but an odd
+    // extent (a sub-view with ld > extent) the float4 that straddles the last stored element of the LAST row would read
+    // up to 12 bytes past a (rows - 1) * ld + extent allocation -- the ABI only demands ld >= extent
+    const bool a_vec = aligned16(A) && lda % 4 == 0 && (trans_a ? M : K) % 4 == 0;
+    const bool b_vec = aligned16(B) && ldb % 4 == 0 && (trans_b ? K : N) % 4 == 0;
     const bool a_kc = !trans_a, b_kc = trans_b != 0;
     const int bn = N > 64 ? 128 : 64;
     const dim3 grid((M + BM - 1) / BM, (N + bn - 1) / bn, sp.splits);

@@ -37,7 +37,9 @@ MGGCN_API mggcn_stream_t mggcn_stream_create(int high_priority) {
 }
 
 MGGCN_API void mggcn_stream_destroy(mggcn_stream_t stream) {
-    if (stream) MGGCN_CHECK_HIP(hipStreamDestroy(as_stream(stream)));
+    if (!stream) return;
+    mggcn_stream_release_scratch(stream);                  // per-stream reduction scratch (elementwise.hip)
+    MGGCN_CHECK_HIP(hipStreamDestroy(as_stream(stream)));
 }
 
 MGGCN_API void mggcn_stream_synchronize(mggcn_stream_t stream) {

@@ -799,53 +799,121 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     vrows.reserve((size_t)n_rows + 4096);
     std::vector<SweepSplitRow> split_rows;
     uint32_t n_slots = 0;
-    for (uint32_t r = 0; r < n_rows; r++) {
-        const uint32_t b = indptr[r], e = indptr[r + 1];
-        MGGCN_REQUIRE(e >= b, "indptr must be non-decreasing");
-        const uint32_t len = e - b;
-        if (len <= split + split / 2) {
-            vrows.push_back({r, b, e, r, 1u});
-        } else {
-            // A heavy row is cut into INTERLEAVED slices (slice k = entries k, k + parts, k + 2 parts, ...), not into
-            // contiguous ranges: a dataset written by scipy / the reference's prep.py, and every transposed matrix, holds
-            // its rows sorted by column, so a contiguous slice covers 1 / parts of the column space -- its wave sweeps
-            // a few panels only, out of step with every other wave of the chip (the premise of the sweep).  Measured on
-            // the symmetric Reddit stand-in: d = 128 SpMM 3.09 ms with contiguous slices against 2.36 with the same
-            // rows shuffled (profiles/experiments/symmetric_r03.log); interleaved, every slice sees the whole column
-            // distribution of its row whatever the order.
-            const uint32_t parts = (len + split - 1) / split;
-            split_rows.push_back({r, n_slots, parts, 0});
-            for (uint32_t k = 0; k < parts; k++) vrows.push_back({r, b + k, e, kSlotFlag | n_slots++, parts});
+    uint32_t T = 0;
+    std::vector<std::vector<uint32_t>> bins;
+    // EXPERIMENT (MGGCN_SPMM_XCD_COLUMNS=1, wide form only): a column partition across the 8 XCDs.
+    // Every row is cut into 8 column slices (entries regrouped by slice), every slice of every row gets a partial-sum
+    // slot, tasks hold rows of ONE slice, and the task table is laid out so that the workgroups the dispatcher deals to
+    // XCD x (block index mod 8 == x) only ever touch slice x of B: each XCD's L2 pulls 1/8 of B per round of resident
+    // tasks instead of all of it.  The price: 8 partial rows per output row (written, then summed by
+    // sweep_combine_kernel) and 8x as many one-wave tasks.  Kernels unchanged.  profiles/experiments/xcd_columns_r03.log.
+    const uint32_t XS = (!narrow && env_u32("MGGCN_SPMM_XCD_COLUMNS", 0u) && n_cols >= 8u * panel_rows) ? 8u : 1u;
+    const uint32_t xs_width = (n_cols + XS - 1) / XS;
+    std::vector<uint32_t> idx2;
+    std::vector<float> val2;
+    const uint32_t *ix = indices;
+    const float *vv = values;
+    auto lpt = [&](const std::vector<uint32_t> &members, uint32_t n_bins, auto &&bin_of) {
+        // equal-work bins of <= cap_rows virtual rows: longest first into the lightest bin
+        std::vector<uint32_t> order(members);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return vrows[a].len() > vrows[b].len(); });
+        std::vector<uint64_t> load(n_bins, 0);
+        using HeapItem = std::pair<uint64_t, uint32_t>;        // (load, bin): smallest load first, then lowest id
+        std::priority_queue<HeapItem, std::vector<HeapItem>, std::greater<HeapItem>> heap;
+        for (uint32_t t = 0; t < n_bins; t++) heap.push({0, t});
+        for (uint32_t vi : order) {
+            MGGCN_REQUIRE(!heap.empty(), "sweep plan: task capacity exhausted");
+            const HeapItem top = heap.top();
+            heap.pop();
+            const uint32_t t = top.second;
+            auto &bin = bins[bin_of(t)];
+            bin.push_back(vi);
+            load[t] += vrows[vi].len();
+            if (bin.size() < (size_t)cap_rows) heap.push({load[t], t});
         }
+    };
+    if (XS == 1) {
+        for (uint32_t r = 0; r < n_rows; r++) {
+            const uint32_t b = indptr[r], e = indptr[r + 1];
+            MGGCN_REQUIRE(e >= b, "indptr must be non-decreasing");
+            const uint32_t len = e - b;
+            if (len <= split + split / 2) {
+                vrows.push_back({r, b, e, r, 1u});
+            } else {
+                // A heavy row is cut into INTERLEAVED slices (slice k = entries k, k + parts, k + 2 parts, ...), not into
+                // contiguous ranges: a dataset written by scipy / the reference's prep.py, and every transposed matrix, holds
+                // its rows sorted by column, so a contiguous slice covers 1 / parts of the column space -- its wave sweeps
+                // a few panels only, out of step with every other wave of the chip (the premise of the sweep).  Measured on
+                // the symmetric Reddit stand-in: d = 128 SpMM 3.09 ms with contiguous slices against 2.36 with the same
+                // rows shuffled (profiles/experiments/symmetric_r03_*.log); interleaved, every slice sees the whole column
+                // distribution of its row whatever the order.
+                const uint32_t parts = (len + split - 1) / split;
+                split_rows.push_back({r, n_slots, parts, 0});
+                for (uint32_t k = 0; k < parts; k++) vrows.push_back({r, b + k, e, kSlotFlag | n_slots++, parts});
+            }
+        }
+        // 2. tasks
+        T = (uint32_t)((vrows.size() + cap_rows - 1) / cap_rows);
+        if (T > round_tasks) T = (T + round_tasks - 1) / round_tasks * round_tasks;
+        T = std::max<uint32_t>(T, 1u);
+        bins.resize(T);
+        std::vector<uint32_t> all(vrows.size());
+        for (size_t i = 0; i < all.size(); i++) all[i] = (uint32_t)i;
+        lpt(all, T, [](uint32_t t) { return t; });
+    } else {
+        // regroup every row's entries by column slice (stable): sub-row (r, s) = [sub[r*XS+s], sub[r*XS+s+1])
+        idx2.resize(nnz);
+        val2.resize(nnz);
+        std::vector<uint32_t> sub((size_t)n_rows * XS + 1, 0u);
+        for (uint32_t r = 0; r < n_rows; r++)
+            for (uint32_t e = indptr[r]; e < indptr[r + 1]; e++) {
+                MGGCN_REQUIRE(indices[e] < n_cols, "column index out of range");
+                sub[(size_t)r * XS + indices[e] / xs_width + 1]++;
+            }
+        for (size_t k = 0; k + 1 < sub.size(); k++) sub[k + 1] += sub[k];
+        {
+            std::vector<uint32_t> cur(sub.begin(), sub.end() - 1);
+            for (uint32_t r = 0; r < n_rows; r++)
+                for (uint32_t e = indptr[r]; e < indptr[r + 1]; e++) {
+                    const uint32_t at = cur[(size_t)r * XS + indices[e] / xs_width]++;
+                    idx2[at] = indices[e];
+                    val2[at] = values[e];
+                }
+        }
+        ix = idx2.data();
+        vv = val2.data();
+        const uint32_t t_est_x = (uint32_t)(((uint64_t)n_rows * XS + cap_rows - 1) / cap_rows);
+        const uint32_t split_x = std::max<uint32_t>(256u, (uint32_t)std::max<uint64_t>(1, nnz / t_est_x) / 2);
+        std::vector<std::vector<uint32_t>> by_slice(XS);
+        for (uint32_t r = 0; r < n_rows; r++) {
+            const uint32_t first = n_slots;
+            for (uint32_t sl = 0; sl < XS; sl++) {
+                const uint32_t b = sub[(size_t)r * XS + sl], e = sub[(size_t)r * XS + sl + 1], len = e - b;
+                if (!len) continue;
+                const uint32_t parts = len <= split_x + split_x / 2 ? 1u : (len + split_x - 1) / split_x;
+                for (uint32_t k = 0; k < parts; k++) {
+                    by_slice[sl].push_back((uint32_t)vrows.size());
+                    vrows.push_back({r, b + k, e, kSlotFlag | n_slots++, parts});
+                }
+            }
+            split_rows.push_back({r, first, n_slots - first, 0});        // every row is combined from its slices (0 slots: C = beta C)
+        }
+        uint32_t Ts = 1;
+        for (const auto &m : by_slice) Ts = std::max<uint32_t>(Ts, (uint32_t)((m.size() + cap_rows - 1) / cap_rows));
+        const uint32_t per_round = round_tasks / XS;                      // tasks of one slice per launch
+        Ts = Ts > per_round ? (Ts + per_round - 1) / per_round * per_round : (Ts + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
+        T = Ts * XS;
+        bins.resize(T);
+        // task q of slice sl sits in block (q / 4) * XS + sl: the dispatcher deals block b to XCD b mod 8
+        for (uint32_t sl = 0; sl < XS; sl++)
+            lpt(by_slice[sl], Ts, [&](uint32_t q) { return ((q / kWavesPerBlock) * XS + sl) * kWavesPerBlock + q % kWavesPerBlock; });
     }
-    // 2. tasks: equal-work bins of <= RW virtual rows (longest first into the lightest bin)
-    uint32_t T = (uint32_t)((vrows.size() + cap_rows - 1) / cap_rows);
-    if (T > round_tasks) T = (T + round_tasks - 1) / round_tasks * round_tasks;
-    T = std::max<uint32_t>(T, 1u);
-    std::vector<uint32_t> order(vrows.size());
-    for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        return vrows[a].len() > vrows[b].len();
-    });
-    std::vector<std::vector<uint32_t>> bins(T);
-    std::vector<uint64_t> load(T, 0);
-    using HeapItem = std::pair<uint64_t, uint32_t>;        // (load, task): smallest load first, then lowest id
-    std::priority_queue<HeapItem, std::vector<HeapItem>, std::greater<HeapItem>> heap;
-    for (uint32_t t = 0; t < T; t++) heap.push({0, t});
-    for (uint32_t vi : order) {
-        MGGCN_REQUIRE(!heap.empty(), "sweep plan: task capacity exhausted");
-        const HeapItem top = heap.top();
-        heap.pop();
-        const uint32_t t = top.second;
-        bins[t].push_back(vi);
-        load[t] += vrows[vi].len();
-        if (bins[t].size() < (size_t)cap_rows) heap.push({load[t], t});
-    }
+    auto task_col_base = [&](uint32_t t) { return XS == 1 ? 0u : ((t / kWavesPerBlock) % XS) * xs_width; };
     // 3. entry stream per task, sorted by (column panel, local row), original order inside a run.
     //    Every (panel,row) run is padded to an EVEN number of entries (a zero-valued copy of its
     //    last entry) and the two entries of each consecutive pair are ordered by column: the
     //    float4 kernel gathers one pair per instruction, one entry per half-wave.
-    const uint32_t n_panels = (n_cols + panel_rows - 1) / panel_rows;
+    const uint32_t n_panels = ((XS == 1 ? n_cols : xs_width) + panel_rows - 1) / panel_rows;
     unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     if (const char *s = std::getenv("MGGCN_HOST_THREADS")) hw = std::max(1u, (unsigned)std::strtoul(s, nullptr, 10));
     const unsigned NT = nnz > (1u << 22) ? hw : 1u;
@@ -859,11 +927,12 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     auto count_buckets = [&](uint32_t t, std::vector<uint32_t> &cnt) {
         std::fill(cnt.begin(), cnt.end(), 0u);
         const auto &bin = bins[t];
+        const uint32_t base = task_col_base(t);
         for (size_t r = 0; r < bin.size(); r++) {
             const VRow &v = vrows[bin[r]];
             for (uint32_t e = v.beg; e < v.end; e += v.step) {
-                MGGCN_REQUIRE(indices[e] < n_cols, "column index out of range");
-                cnt[(size_t)(indices[e] / panel_rows) * kRW + r]++;
+                MGGCN_REQUIRE(ix[e] < n_cols, "column index out of range");
+                cnt[(size_t)((ix[e] - base) / panel_rows) * kRW + r]++;
             }
         }
     };
@@ -936,13 +1005,14 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
             std::copy(start.begin(), start.begin() + n_buckets, cur.begin());
             uint2 *out = entries.data() + tasks[t].beg;
             const auto &bin = bins[t];
+            const uint32_t base = task_col_base(t);
             for (size_t r = 0; r < bin.size(); r++) {
                 const VRow &v = vrows[bin[r]];
                 for (uint32_t e = v.beg; e < v.end; e += v.step) {
-                    const uint32_t c = indices[e];
-                    const uint32_t at = cur[(size_t)(c / panel_rows) * kRW + r]++;
+                    const uint32_t c = ix[e];
+                    const uint32_t at = cur[(size_t)((c - base) / panel_rows) * kRW + r]++;
                     uint32_t vb;
-                    std::memcpy(&vb, &values[e], 4);
+                    std::memcpy(&vb, &vv[e], 4);
                     out[at] = make_uint2((((uint32_t)r & (kRW - 1)) << kColBits) | c, vb);
                 }
             }

@@ -278,6 +278,29 @@ def synth_reddit_like(scale: float = 1.0, seed: int = 1, symmetric: bool = False
     return (indptr, indices, data), X, Y
 
 
+PRODUCTS_SHAPE = dict(n=2_449_032, nnz=126_200_000, features=128, classes=47, max_deg=17_500)
+
+
+def synth_products_like(scale: float = 1.0, seed: int = 5, symmetric: bool = True):
+    """ogbn-products' public shape (BASELINE.json configs[3]; SURVEY.md 8: n = 2 449 032 after padding to a multiple
+    of 8, ~126.2 M non-zeros with both directions + self-loops, mean degree 51; features 100 padded to 128 as
+    prep.py:122-124 does, 47 classes -> 48 at P = 8): B = n x 128 floats = 1.25 GB >> Infinity Cache, so the SpMM is
+    HBM-bound here.  The OGB graph is undirected, hence symmetric by default."""
+    n = int(PRODUCTS_SHAPE["n"] * scale) // 8 * 8
+    nnz = int(PRODUCTS_SHAPE["nnz"] * scale)
+    max_deg = int(max(4 * nnz / max(n, 1) + 8, PRODUCTS_SHAPE["max_deg"] * min(1.0, scale * 4)))
+    if symmetric:
+        nnz -= (nnz - n) % 2
+        indptr, indices, data = synth_symmetric_powerlaw_csr(n, nnz, min(max_deg, n - 1), seed)
+    else:
+        indptr, indices, data = synth_powerlaw_csr(n, nnz, max_deg, seed)
+    rng = np.random.default_rng(seed + 1)
+    X = rng.standard_normal((n, PRODUCTS_SHAPE["features"]), dtype=np.float32)
+    Y = rng.integers(0, PRODUCTS_SHAPE["classes"], size=(n, 1)).astype(np.int32)
+    Y[0, 0] = PRODUCTS_SHAPE["classes"] - 1
+    return (indptr, indices, data), X, Y
+
+
 # ----------------------------------------------------------------------------
 # Data preparation without DGL (SURVEY.md section 8(f) rank 3): what the reference's
 # test/data/prep.py does to a graph before writing it (serialize_dgl_graph :100-126 and

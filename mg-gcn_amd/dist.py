@@ -289,6 +289,9 @@ class dist_context(host_comm):
     def __init__(self, overlap: bool = True, device_index: Optional[int] = None, group=None):
         host_comm.__init__(self, group)
         self.overlap = overlap
+        # bench.py's exchange pass: extra events around every exchange (comm-stream time of the collectives, time the
+        # compute stream spends waiting for each piece).  Off in timed epochs: ~10 more event records per SpMM.
+        self.profile_exchange = False
         if device_index is None:
             device_index = self.rank % max(_lib.require_gpu(), 1)
         self.ctx = context(device_index)
@@ -615,11 +618,21 @@ class dist_sparse_linear:
                 g, piece = views[c]
                 gathered.append(g)
                 pend.append(dctx.all_gather_rows(piece, g.t, cs))
+            prof = dctx.profile_exchange
+            if prof:                                           # comm-stream time of the whole exchange
+                for c in range(K):
+                    pend[c].wait(cs)
+                ctx.record(name + "matmul-exchange-end", cs)
+                ctx.register_timer(name + "matmul-exchange", name + "0_matmul-bcast-start", name + "matmul-exchange-end")
             # local block first: no dependency on the exchange
             last_local = flags if P == 1 else 0
             ops._spmm(ctx, A.diag, B.local, C.local, self._plan(ctx, (tag, "diag"), A.diag, d), 1.0, beta,
                       last_local)
             for c in range(K):                                 # piece c multiplies while piece c+1 is on the wire
+                if prof:                                       # how long the compute stream stalls for piece c
+                    ctx.record(name + f"{c}_matmul-bcast-ready", 0)
+                    ctx.register_timer(name + f"{c}_matmul-bcast-wait", name + f"{c}_matmul-bcast-ready",
+                                       name + f"{c}_matmul-bcast-finish")
                 pend[c].wait(0)                                # also at P == 1: the buffer is reused by the next call
                 ctx.record(name + f"{c}_matmul-bcast-finish", 0)
                 if P > 1:
@@ -640,9 +653,16 @@ class dist_sparse_linear:
             pend = None
             if P > 1:
                 pend = dctx.all_to_all_rows(send.t[:n_send], recv.t[:n_recv], h["send_rows"], h["recv_rows"], cs)
+                if dctx.profile_exchange:
+                    pend.wait(cs)
+                    ctx.record(name + "matmul-exchange-end", cs)
+                    ctx.register_timer(name + "matmul-exchange", name + "0_matmul-bcast-start", name + "matmul-exchange-end")
             ops._spmm(ctx, A.diag, B.local, C.local, self._plan(ctx, (tag, "diag"), A.diag, d), 1.0, beta,
                       flags if P == 1 else 0)
             if P > 1:
+                if dctx.profile_exchange:
+                    ctx.record(name + "0_matmul-bcast-ready", 0)
+                    ctx.register_timer(name + "0_matmul-bcast-wait", name + "0_matmul-bcast-ready", name + "0_matmul-bcast-finish")
                 pend.wait(0)
                 ctx.record(name + "0_matmul-bcast-finish", 0)
                 blk = h["remote"]
@@ -654,6 +674,12 @@ class dist_sparse_linear:
                     ctx.wait(name + f"{i - 1}_matmul-spmm", cs)      # double-buffer hazard (:66-67)
                 ctx.record(name + f"{i}_matmul-bcast-start", cs)
                 pend = dctx.broadcast_rows(B.local.t, bufs[i % 2].t, i, cs)
+                if dctx.profile_exchange:
+                    pend.wait(cs)
+                    ctx.record(name + f"{i}_matmul-exchange-end", cs)
+                    ctx.register_timer(name + f"{i}_matmul-exchange", name + f"{i}_matmul-bcast-start", name + f"{i}_matmul-exchange-end")
+                    ctx.record(name + f"{i}_matmul-bcast-ready", 0)
+                    ctx.register_timer(name + f"{i}_matmul-bcast-wait", name + f"{i}_matmul-bcast-ready", name + f"{i}_matmul-bcast-finish")
                 pend.wait(0)
                 ctx.record(name + f"{i}_matmul-bcast-finish", 0)
                 blk = A.blocks[i]

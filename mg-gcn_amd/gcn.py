@@ -324,7 +324,7 @@ class softmax_cross_entropy_loss:
             self.sums = host_scalars(2) if self.host_sums else torch.empty(2, dtype=torch.float32, device=ctx.device)
         if self.fused:
             if self.copy:                       # the reference copies, then works in place (gcn.hpp:653-656): here the
-                if self.G is None:              # pass reads the logits and writes the gradient elsewhere
+                if self.G is None or self.G.shape() != H.shape():   # pass reads the logits, writes the gradient elsewhere
                     self.G = dn_matrix(H.n(), H.m())
             else:
                 self.G = H

@@ -575,7 +575,7 @@ public:
         if (!sums_) sums_ = mggcn::host_malloc<r_t>(2);          // written by the kernels, read by the host after its sync
         if (fused) {
             if (copy) {                       // reference: copy, then in place (:653-656); here the pass writes elsewhere
-                if (!G.buffer()) G = dn_matrix<r_t>(H.n(), H.m());
+                if (!G.buffer() || G.shape() != H.shape()) G = dn_matrix<r_t>(H.n(), H.m());
             } else {
                 G = H;
             }

@@ -50,6 +50,16 @@ class context:
         self.timers: Dict[str, Tuple[str, str]] = {}
         self._workspace = None
 
+    def __del__(self):
+        # the library keeps a small reduction scratch per (device, stream): hand it back with the streams, so that a
+        # recycled stream handle never inherits it (torch owns the streams; the ABI's own streams do this on destroy)
+        try:
+            self.lib.mggcn_set_device(self.rank)
+            for st in self.cuda_streams:
+                self.lib.mggcn_stream_release_scratch(st.cuda_stream)
+        except Exception:
+            pass
+
     # -- device / stream ----------------------------------------------------
     def set(self) -> None:
         self.lib.mggcn_set_device(self.rank)

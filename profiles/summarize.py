@@ -17,8 +17,11 @@ import collections
 import csv
 import json
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from bench import spmm_kernel_sha  # noqa: E402  (content hash of csrc/spmm*.hip: stamps the counters' kernel version)
 
 
 def per_kernel(path):
@@ -72,6 +75,7 @@ def main():
         if mk and "FETCH_SIZE" in mk and "WRITE_SIZE" in mk:
             traffic = int((2 * mk["FETCH_SIZE"] + mk["WRITE_SIZE"]) * 1024 * a.launches_per_unit)
             rec = {"kernel": a.main_kernel, "bytes_per_call": traffic, "source": f"profiles/{a.tag}_summary.md",
+                   "kernel_source_sha": spmm_kernel_sha(),
                    "kernel_launches_per_spmm_call": a.launches_per_unit,
                    "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 per kernel launch x launches per "
                               "SpMM call (gfx950: FETCH_SIZE halves wide coalesced reads); separate --pmc passes"}

@@ -52,3 +52,62 @@ def pkg():
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+# ------------------------------------------------------------------------------------------------
+# The Reddit-shaped workloads at FULL size (BASELINE.json configs[1..2]), shared by the -m gpu tests:
+#   "asym"  the SURVEY.md 8(d) stand-in the headline numbers are quoted on (power-law rows, random columns),
+#   "sym"   pattern A = A^T like the real dataset (both directions of a simple graph + self-loops; rows sorted).
+# Generated once per session; the oracle epochs (fp32 restatement and exact-accumulation twin) are cached per
+# (stand-in, class count) -- ~12 s of host time each.
+# ------------------------------------------------------------------------------------------------
+REDDIT_HIDDEN = [128, 128, 128]
+_reddit_cache = {}
+_oracle_cache = {}
+
+
+def reddit_standin(pkg, kind):
+    if kind not in _reddit_cache:
+        (ip, ix, dv), X, Y = pkg.datasets.synth_reddit_like(1.0, seed=1, symmetric=(kind == "sym"))
+        n = ip.shape[0] - 1
+        assert (n, int(ip[-1])) == (232_968, 114_848_860)            # test/test_matrix.cpp:48-58
+        _reddit_cache[kind] = dict(kind=kind, ip=ip, ix=ix, dv=dv, X=X, Y=Y, n=n)
+    return _reddit_cache[kind]
+
+
+def reddit_oracle_epoch(orc, data, classes, f64acc):
+    """ONE epoch (forward, loss, backward) of oracle.Gcn at the full shape with `classes` logits columns
+    (41, or the padded 44 / 48 of src/main.cpp:135): loss, acc, gradients, the seed-99 parameters."""
+    key = (data["kind"], classes, f64acc)
+    if key not in _oracle_cache:
+        sizes = [data["X"].shape[1]] + REDDIT_HIDDEN + [classes]
+        O = orc.Gcn(orc.Csr(data["ip"], data["ix"], data["dv"], data["n"]), sizes, f64acc=f64acc)
+        loss, acc = O.train_forward(data["X"], data["Y"])
+        O.backward()
+        _oracle_cache[key] = dict(loss=loss, acc=acc, grads=[(l.lin.G_W.copy(), l.lin.G_b.copy()) for l in O.layers],
+                                  W=[(l.lin.W.copy(), l.lin.b.copy()) for l in O.layers])
+        del O
+    return _oracle_cache[key]
+
+
+@pytest.fixture(scope="session", params=["asym", "sym"])
+def reddit_any(request, pkg):
+    return reddit_standin(pkg, request.param)
+
+
+@pytest.fixture(scope="session")
+def reddit_dirs(pkg, tmp_path_factory):
+    """kind -> directory holding the stand-in in the reference's on-disk format (graph.bin / features.bin /
+    labels.bin / sets.bin under permuted/<name>, test/data/prep.py:78-99), written on first use"""
+    base = tmp_path_factory.mktemp("reddit_full")
+    made = {}
+
+    def get(kind):
+        if kind not in made:
+            d = reddit_standin(pkg, kind)
+            path = os.path.join(str(base), "permuted", f"reddit_{kind}")
+            pkg.datasets.write_dataset(path, d["ip"], d["ix"], d["dv"], d["X"], d["Y"])
+            made[kind] = path
+        return made[kind]
+    get.base = str(base)
+    return get

@@ -32,6 +32,11 @@ def test_bench_single_gpu_prints_one_json_line():
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["loss_matches_gpu_first"] is True
     assert out["loss_first_last"][1] < out["loss_first_last"][0]
+    # extra keys, never the headline: the reference's own interface on the same workload and the symmetric stand-in
+    assert out["cli_epoch_ms"] > 0 and out["cli_setup_s"] >= 0 and out["cli_epochs"] == 8
+    assert abs(out["cli_loss_first"] - out["loss_first_last"][0]) <= 1e-4 * out["loss_first_last"][0]   # same model, same data
+    assert out["symmetric_epoch_ms"] > 0 and out["symmetric_spmm_ms_per_call"] > 0
+    assert isinstance(rf["traffic_kernel_source_current"], bool)
 
 
 @pytest.mark.gpu
@@ -45,3 +50,9 @@ def test_bench_multi_rank_rehearsal_prints_one_json_line():
     assert REQUIRED <= set(out)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["parallelism"].startswith("rows2")
     assert out["loss_first_last"][1] < out["loss_first_last"][0]
+    # the line says what it exchanged over (the first hardware SCALE run must be self-explaining)
+    comm = out["comm"]
+    assert comm["backend"] == "gloo" and comm["world_size"] == 2 and comm["rehearsal_gloo_on_one_gpu"] is True
+    assert [d["rank"] for d in comm["devices"]] == [0, 1] and all("name" in d and "device" in d for d in comm["devices"])
+    assert comm["mode"] == "allgather" and comm["overlap"] is True and "rccl_version" in comm
+    assert comm["exchange_ms"] > 0 and comm["exposed_ms"] >= 0 and comm["overlap_frac"] is not None

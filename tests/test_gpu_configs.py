@@ -35,16 +35,26 @@ def ctx(pkg):
     return pkg.context(0)
 
 
+def _with_matrices(pkg, data):
+    """adds the two normalised matrices to a conftest stand-in (cached on the dict)"""
+    if "A" not in data:
+        A = pkg.csr_matrix(data["ip"], data["ix"], data["dv"].copy(), data["n"])
+        A.normalize(True)                        # backward matrix  A D^-1
+        data["A"], data["A_T"] = A, A.transpose()  # forward matrix  (A D^-1)^T
+    return data
+
+
 @pytest.fixture(scope="module")
 def reddit(pkg):
-    """the bench workload: graph + features + labels, and the two normalised matrices"""
-    (ip, ix, dv), X, Y = pkg.datasets.synth_reddit_like(1.0, seed=1)
-    n = ip.shape[0] - 1
-    assert (n, int(ip[-1])) == (232_968, 114_848_860)
-    A = pkg.csr_matrix(ip, ix, dv.copy(), n)
-    A.normalize(True)                        # backward matrix  A D^-1        (power-law rows)
-    A_T = A.transpose()                      # forward matrix  (A D^-1)^T    (hot columns)
-    return dict(ip=ip, ix=ix, dv=dv, X=X, Y=Y, n=n, A=A, A_T=A_T)
+    """the bench workload (SURVEY.md 8(d) stand-in): graph + features + labels, and the two normalised matrices"""
+    from conftest import reddit_standin
+    return _with_matrices(pkg, reddit_standin(pkg, "asym"))
+
+
+@pytest.fixture(scope="module")
+def reddit_both(pkg, reddit_any):
+    """both stand-ins in turn: the SURVEY one and the symmetric one with the real dataset's structure"""
+    return _with_matrices(pkg, reddit_any)
 
 
 def sample_rows(M, k, rng, lo=0, hi=None):
@@ -76,31 +86,20 @@ def assert_rows_close(got, want, what):
 # ------------------------------------------------------------------------------------------------
 # C2
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def reddit_oracle_epoch(oracle, reddit):
-    """ONE epoch of the oracle at the full shape, twice: the fp32 restatement (what the CPU baseline
-    times) and its exact-accumulation twin (oracle.Gcn(f64acc=True): same algorithm, every SpMM / GEMM sum
-    in fp64, rounded once).  Over K = n = 232 968 terms the fp32 restatement's own sequential sums are
-    1.5e-4 away from the exact ones (layer 0 G_b = 1^T G: measured, see the assertion below) -- more than the
-    1e-4 bar -- so the device is judged against the exact twin and against the fp32 restatement within
-    the restatement's own distance.  ~7 s + ~5 s on the box's 16 cores; shared by the fused and unfused run."""
-    out = {}
-    for key, f64 in (("f32", False), ("f64acc", True)):
-        O = oracle.Gcn(oracle.Csr(reddit["ip"], reddit["ix"], reddit["dv"], reddit["n"]), SIZES, f64acc=f64)
-        loss, acc = O.train_forward(reddit["X"], reddit["Y"])
-        O.backward()
-        out[key] = dict(loss=loss, acc=acc, grads=[(l.lin.G_W.copy(), l.lin.G_b.copy()) for l in O.layers],
-                        W=[(l.lin.W.copy(), l.lin.b.copy()) for l in O.layers])
-        del O
-    return out
-
-
 @pytest.mark.parametrize("fused", [True, False])
-def test_c2_full_epoch_matches_oracle(pkg, ctx, reddit, reddit_oracle_epoch, fused):
+def test_c2_full_epoch_matches_oracle(pkg, oracle, ctx, reddit_both, fused):
     """src/gcn.hpp:437-489, :785-818 at BASELINE.json configs[1]: forward, loss, backward of the whole
-    model; fused = the kernels bench.py times, unfused = the reference's launch sequence."""
+    model; fused = the kernels bench.py times, unfused = the reference's launch sequence.  On BOTH stand-ins.
+    The judge is the oracle twice: the fp32 restatement (what the CPU baseline times) and its exact-accumulation
+    twin (oracle.Gcn(f64acc=True): same algorithm, every SpMM / GEMM sum in fp64, rounded once).  Over
+    K = n = 232 968 terms the fp32 restatement's own sequential sums are 1.5e-4 away from the exact ones (layer 0
+    G_b = 1^T G: measured) -- more than the 1e-4 bar -- so the device is judged against the exact twin and
+    against the fp32 restatement within the restatement's own distance.  ~7 s + ~5 s per stand-in, cached."""
+    from conftest import reddit_oracle_epoch
+    reddit = reddit_both
     n = reddit["n"]
-    exact, f32 = reddit_oracle_epoch["f64acc"], reddit_oracle_epoch["f32"]
+    exact = reddit_oracle_epoch(oracle, reddit, SIZES[-1], True)
+    f32 = reddit_oracle_epoch(oracle, reddit, SIZES[-1], False)
     G = pkg.gcn(pkg.csr_matrix(reddit["ip"], reddit["ix"], reddit["dv"].copy(), n), SIZES, fused=fused)
     for layer, (W, b) in zip(G.layers(), exact["W"]):                     # same seed-99 init, bit for bit
         np.testing.assert_array_equal(layer.W().numpy(), W)
@@ -115,9 +114,9 @@ def test_c2_full_epoch_matches_oracle(pkg, ctx, reddit, reddit_oracle_epoch, fus
     for li, layer in enumerate(G.layers()):
         for k, (what, got) in enumerate((("G_W", layer.GW().numpy()), ("G_b", layer.Gb().numpy()))):
             e = relerr(got, exact["grads"][li][k])
-            assert e <= TOL, (li, what, e)
+            assert e <= TOL, (reddit["kind"], li, what, e)
             own = relerr(f32["grads"][li][k], exact["grads"][li][k])      # the fp32 restatement's own error
-            assert relerr(got, f32["grads"][li][k]) <= TOL + own, (li, what, own)
+            assert relerr(got, f32["grads"][li][k]) <= TOL + own, (reddit["kind"], li, what, own)
     # the plans the model built are the full-size forms: sweep tasks for both matrices
     for layer in G.layers():
         assert layer.A.ext_buffer.num_sweep_tasks() > 0
@@ -126,10 +125,11 @@ def test_c2_full_epoch_matches_oracle(pkg, ctx, reddit, reddit_oracle_epoch, fus
 
 @pytest.mark.parametrize("which", ["forward", "backward"])
 @pytest.mark.parametrize("d", [128, 41])
-def test_c2_spmm_sampled_rows_fp64(pkg, ctx, reddit, which, d):
+def test_c2_spmm_sampled_rows_fp64(pkg, ctx, reddit_both, which, d):
     """d = 128: spmm_sweep_pair_kernel (71 % of the epoch); d = 41: sweep_repack + spmm_sweep_quad_lds_kernel
     (15 %), both on the hot-column forward matrix and on the power-law-row backward matrix, with the plan
     the layer would build (get_matmul_buffer with the layer's width; max_d = 128 as sparse_linear asks)."""
+    reddit = reddit_both
     n = reddit["n"]
     M = reddit["A_T"] if which == "forward" else reddit["A"]
     rng = np.random.default_rng(d + (which == "forward"))
@@ -242,6 +242,38 @@ def test_c4_products_shape(pkg, ctx):
     assert torch.equal(C2.t, 2 * C.t)                                      # linearity, exact for a power of two
     del B2, C2, Bd, C, buf
     rank_share_check(pkg, ctx, M, 8, 5, 4, d, seed=41)
+
+
+def test_c4_products_full_epoch_matches_oracle(pkg, oracle, ctx):
+    """BASELINE.json configs[3] as a PATH, not a product: one full training epoch (forward, loss, backward) of the
+    128-128-128-128-48 GCN on the products-shaped graph (undirected like the OGB one: pattern A = A^T, rows sorted;
+    n = 2 449 032, 126.2 M non-zeros; 47 classes padded to 48 as at P = 8, src/main.cpp:135) on one GPU -- row-split
+    SpMM (the sweep form is gated off at mean degree 51), GEMMs with M = 2.45 M rows, the fused loss over 2.45 M rows --
+    against the exact-accumulation oracle: loss and every G_W / G_b at 1e-4."""
+    (ip, ix, dv), X, Y = pkg.datasets.synth_products_like(1.0, seed=5, symmetric=True)
+    n = ip.shape[0] - 1
+    assert (n, int(ip[-1])) == (2_449_032, 126_200_000)
+    sizes = [X.shape[1], 128, 128, 128, 48]
+    O = oracle.Gcn(oracle.Csr(ip, ix, dv, n), sizes, f64acc=True)
+    want_loss, want_acc = O.train_forward(X, Y)
+    O.backward()
+    want = [(l.lin.G_W.copy(), l.lin.G_b.copy()) for l in O.layers]
+    del O
+    G = pkg.gcn(pkg.csr_matrix(ip, ix, dv.copy(), n), sizes, fused=True)
+    Xd, Yd = pkg.dn_matrix.from_numpy(X), pkg.dn_matrix.from_numpy(Y)
+    loss, acc = G.train_forward(ctx, Xd, Yd)
+    G.backward(ctx)
+    ctx.sync()
+    assert abs(loss - want_loss) <= TOL * abs(want_loss), (loss, want_loss)
+    assert abs(acc - want_acc) <= 16.0 / n
+    for li, (layer, (gw, gb)) in enumerate(zip(G.layers(), want)):
+        assert relerr(layer.GW().numpy(), gw) <= TOL, (li, "G_W")
+        assert relerr(layer.Gb().numpy(), gb) <= TOL, (li, "G_b")
+        assert layer.A.ext_buffer.num_sweep_tasks() == 0            # the row-split form is what ran
+    loss1, _ = G.train_step(ctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+    loss2, _ = G.train_step(ctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+    assert loss1 == pytest.approx(loss, rel=1e-6) and loss2 < loss1     # same forward again, then it trains
+    del G
 
 
 def test_c5_papers100m_rank_share(pkg, ctx):
