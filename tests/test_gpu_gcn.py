@@ -337,3 +337,41 @@ def test_residual_layer_matches_oracle(pkg, oracle, ctx, fused, sizes):
         G.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
         O.adam_update()
         ctx.sync()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_hoisted_first_aggregation_matches_the_reference_epoch(pkg, oracle, ctx, fused):
+    """gcn(hoist_first_aggregation=True): layer 0's loop-invariant A_fwd . X is computed once, the epoch runs one SpMM
+    fewer ((A_fwd X) W + 1 b^T = A_fwd (X W + 1 b^T) since A_fwd 1 = 1).  Optional mode, never the headline: it must
+    give the unhoisted model's and the oracle's loss and gradients at 1e-4, on the Reddit layer stack."""
+    sizes = [608, 128, 128, 128, 41]
+    n = 2048
+    ip, ix, dv = _graph(pkg, n, n * 24, 1200, seed=77)
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((n, sizes[0]), dtype=np.float32)
+    Y = rng.integers(0, sizes[-1], size=(n, 1)).astype(np.int32)
+    Xd, Yd = pkg.dn_matrix.from_numpy(X), pkg.dn_matrix.from_numpy(Y)
+    O = oracle.Gcn(oracle.Csr(ip, ix, dv, n), sizes)
+    ol, oa = O.train_forward(X, Y)
+    O.backward()
+    got = {}
+    for hoist in (False, True):
+        G = pkg.gcn(pkg.csr_matrix(ip, ix, dv.copy(), n), sizes, fused=fused, hoist_first_aggregation=hoist)
+        assert G.layers()[0].hoist_input is hoist
+        loss, acc = G.train_forward(ctx, Xd, Yd)
+        G.backward(ctx)
+        ctx.sync()
+        got[hoist] = (loss, acc, [(l.GW().numpy().copy(), l.Gb().numpy().copy()) for l in G.layers()])
+        if hoist:
+            loss_again, _ = G.train_forward(ctx, Xd, Yd)             # from the cached A_fwd X: bit for bit the same forward
+            assert loss_again == loss
+            l1, _ = G.train_step(ctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+            l2, _ = G.train_step(ctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+            assert l1 == loss and l2 < l1
+    for hoist in (False, True):
+        loss, acc, grads = got[hoist]
+        assert abs(loss - ol) <= TOL * abs(ol) and abs(acc - oa) <= 3.0 / n
+        for (gw, gb), layer in zip(grads, O.layers):
+            assert relerr(gw, layer.lin.G_W) <= TOL and relerr(gb, layer.lin.G_b) <= TOL
+    for (gw0, gb0), (gw1, gb1) in zip(got[False][2], got[True][2]):
+        assert relerr(gw1, gw0) <= TOL and relerr(gb1, gb0) <= TOL
