@@ -34,7 +34,10 @@ import __graft_entry__ as ge  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBPS = 6300.0    # same guide: measured float4 copy (report against both)
-L1_FILL_PEAK_GBPS = 34900.0     # 256 CUs x 64 B/clk x 2.13 GHz (GRBM_GUI_ACTIVE under the SpMM, profiles/r02_l1_pmc_d128_summary.md)
+# 256 CUs x 64 B/clk x the clock the chip holds under the SpMM: 2.345 GHz inside the bench's own epochs (GRBM_GUI_ACTIVE / 8
+# / kernel duration with no other counter armed, profiles/experiments/epoch_clocks_r03.log; the TCP-counter passes of r02
+# slowed the kernel to 2.13 GHz, which is where the earlier 34.9 TB/s came from)
+L1_FILL_PEAK_GBPS = 38400.0
 
 
 def spmm_bytes_alg(n_rows, n_cols, nnz, d, beta_nonzero=False):
@@ -267,7 +270,7 @@ def main():
                 "ms_per_call": round(avg, 4), "ms_per_call_median": round(med, 4), "ms_per_call_min": round(mn, 4),
                 "kernel_launches_per_call": launches_per_call, "calls_timed": int(a.size), "bytes_alg": b_alg,
                 # what actually bounds the kernel: every gathered row crosses the L2 -> vector-L1 fill
-                # path, 64 B/clk/CU x 256 CUs at the 2.13 GHz the chip holds under this load = 34.9 TB/s
+                # path, 64 B/clk/CU x 256 CUs at the 2.345 GHz the chip holds under this load = 38.4 TB/s
                 "gather_GBps": round(spmm_bytes_gather(nr, nz, d) / (avg * 1e-3) / 1e9, 1),
                 "l1_fill_peak_GBps": L1_FILL_PEAK_GBPS,
                 "l1_fill_frac": round(spmm_bytes_gather(nr, nz, d) / (avg * 1e-3) / 1e9 / L1_FILL_PEAK_GBPS, 4)}

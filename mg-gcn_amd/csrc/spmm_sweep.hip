@@ -916,7 +916,9 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
     const uint32_t n_panels = ((XS == 1 ? n_cols : xs_width) + panel_rows - 1) / panel_rows;
     unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     if (const char *s = std::getenv("MGGCN_HOST_THREADS")) hw = std::max(1u, (unsigned)std::strtoul(s, nullptr, 10));
-    const unsigned NT = nnz > (1u << 22) ? hw : 1u;
+    // threads from 2^19 non-zeros on: a rank's blocks at P = 8 on the Reddit shape hold 1.8-3.2 M each, and the 160 plans of
+    // the single-process form were 5 s of one-thread work inside the first epoch
+    const unsigned NT = nnz > (1u << 19) ? hw : 1u;
     auto run_parallel = [&](auto &&fn) {
         if (NT <= 1) { fn(0u); return; }
         std::vector<std::thread> th;

@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <numeric>
 #include <ostream>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "matrix.hpp"
@@ -90,13 +92,30 @@ inline std::size_t mggcn_default_chunks(std::size_t P) {
 template <typename x_t, typename v_t, typename r_t>
 class dist_row_csr_matrix {
     using matrix_t = csr_matrix<x_t, v_t, r_t>;
-    std::vector<std::vector<matrix_t>> As;
-    std::vector<std::vector<matrix_t>> chunks_;       // [i][c]
-    std::vector<v_t> chunk_bounds_;                    // K + 1 row offsets inside a shard
-    std::vector<matrix_t> halo_remote_;                // [i]
-    std::vector<std::vector<std::vector<v_t>>> need_;  // [i][s]
+    // Shared by the copies of one matrix (the classes are passed by value like the reference's): the block split is
+    // built by the constructor, the two MI355X-first forms on first use -- a model runs ONE schedule, and at the
+    // Reddit shape the halo lists alone (sort + unique + a binary search per non-zero) cost more host time than the
+    // rest of the partition.  Every builder runs one host thread per row block (the reference's constructor is one
+    // serial loop, src/dist_matrix.hpp:215-259; at P = 8 that was 20 s of single-thread work before the first epoch).
+    struct state {
+        std::vector<std::vector<matrix_t>> As;                 // [i][s]
+        std::vector<std::vector<matrix_t>> chunks;             // [i][c]      all-gather schedule, built on first use
+        std::vector<matrix_t> halo_remote;                     // [i]         halo schedule, built on first use
+        std::vector<std::vector<std::vector<v_t>>> need;       // [i][s]
+        std::vector<v_t> chunk_bounds;                         // K + 1 row offsets inside a shard
+        std::once_flag chunks_once, halo_once;
+    };
+    std::shared_ptr<state> st_ = std::make_shared<state>();
     std::vector<v_t> p_;
     std::size_t M_ = 0;
+
+    template <typename F>
+    static void for_each_block(std::size_t P, F &&fn) {
+        if (P <= 1) { for (std::size_t i = 0; i < P; i++) fn(i); return; }
+        std::vector<std::thread> th;
+        for (std::size_t i = 0; i < P; i++) th.emplace_back(fn, i);
+        for (auto &t : th) t.join();
+    }
 
     static std::vector<matrix_t> split_rows(const matrix_t &A, v_t rb, v_t re, const std::vector<v_t> &q) {
         const std::uint32_t nq = (std::uint32_t)q.size() - 1, rows = re - rb;
@@ -124,27 +143,85 @@ class dist_row_csr_matrix {
     }
 
     // The off-diagonal blocks of row block i merged into ONE CSR (row order and, inside a row, source-rank
-    // order then original order kept) with the column of entry (block s, local column l) given by col(s, l).
-    template <typename F>
-    static matrix_t merge_remote(const std::vector<matrix_t> &blocks, std::size_t i, v_t n_cols, F &&col) {
+    // order then original order kept), entry (block s, local column l) kept when keep(l) and given column col(s, l).
+    template <typename K, typename F>
+    static matrix_t merge_remote(const std::vector<matrix_t> &blocks, std::size_t i, v_t n_cols, K &&keep, F &&col) {
         const v_t rows = blocks[0].n();
         std::vector<x_t> ptr(rows + 1, 0);
-        std::vector<v_t> idx;
-        std::vector<r_t> dat;
-        std::size_t total = 0;
-        for (std::size_t s = 0; s < blocks.size(); s++) if (s != i) total += blocks[s].nnz();
-        idx.reserve(total);
-        dat.reserve(total);
-        for (v_t r = 0; r < rows; r++) {
-            for (std::size_t s = 0; s < blocks.size(); s++) {
-                if (s == i) continue;
-                const auto &b = blocks[s];
-                for (auto e = b.begin(r); e < b.end(r); e++) { idx.push_back(col(s, b.indices()[e])); dat.push_back(b.data()[e]); }
-            }
-            ptr[r + 1] = (x_t)idx.size();
+        std::size_t total = 0;                                         // exact count first: no reallocation, no masked copies
+        for (std::size_t s = 0; s < blocks.size(); s++) {
+            if (s == i) continue;
+            const auto &b = blocks[s];
+            for (v_t r = 0; r < rows; r++)
+                for (auto e = b.begin(r); e < b.end(r); e++)
+                    if (keep(b.indices()[e])) { ptr[r + 1]++; total++; }
+        }
+        for (v_t r = 0; r < rows; r++) ptr[r + 1] += ptr[r];
+        std::vector<v_t> idx(total);
+        std::vector<r_t> dat(total);
+        std::vector<x_t> cur(ptr.begin(), ptr.end() - 1);
+        for (std::size_t s = 0; s < blocks.size(); s++) {            // source-rank order inside a row: s ascending
+            if (s == i) continue;
+            const auto &b = blocks[s];
+            for (v_t r = 0; r < rows; r++)
+                for (auto e = b.begin(r); e < b.end(r); e++) {
+                    const v_t l = b.indices()[e];
+                    if (!keep(l)) continue;
+                    const x_t at = cur[r]++;
+                    idx[at] = col(s, l);
+                    dat[at] = b.data()[e];
+                }
         }
         return matrix_t(std::move(ptr), std::move(idx), std::move(dat), n_cols);
     }
+
+    // (a) all-gather schedule: piece c gathers rows cb[c]..cb[c+1] of EVERY shard in rank order, so
+    //     entry (s, l) of piece c = piece_of[l] lands at column s * len_c + (l - cb[c])
+    void build_chunks() const {
+        auto &S = *st_;
+        const std::size_t P = S.As.size(), K = S.chunk_bounds.size() - 1;
+        S.chunks.assign(P, {});
+        for_each_block(P, [&](std::size_t i) {
+            const auto &blocks = S.As[i];
+            for (std::size_t c = 0; c < K; c++) {
+                const v_t lo = S.chunk_bounds[c], hi = S.chunk_bounds[c + 1], len = hi - lo;
+                S.chunks[i].push_back(merge_remote(blocks, i, (v_t)(P * len), [&](v_t l) { return l >= lo && l < hi; },
+                                                   [&](std::size_t s, v_t l) { return (v_t)(s * len + (l - lo)); }));
+            }
+        });
+    }
+
+    // (b) halo schedule: distinct referenced rows per source shard, receive layout in source order
+    void build_halo() const {
+        auto &S = *st_;
+        const std::size_t P = S.As.size();
+        S.need.assign(P, std::vector<std::vector<v_t>>(P));
+        S.halo_remote.assign(P, matrix_t());
+        for_each_block(P, [&](std::size_t i) {
+            const auto &blocks = S.As[i];
+            const v_t shard = blocks[0].n();
+            std::vector<v_t> off(P + 1, 0);
+            // position of every referenced local row in its source's need list: one flag pass, no sort, no search
+            std::vector<std::vector<v_t>> pos(P);
+            for (std::size_t s = 0; s < P; s++) {
+                if (s != i) {
+                    const auto width = blocks[s].m();
+                    std::vector<unsigned char> used(width, 0);
+                    for (const auto l : blocks[s].indices()) used[l] = 1;
+                    pos[s].assign(width, 0);
+                    auto &nd = S.need[i][s];
+                    for (v_t l = 0; l < width; l++)
+                        if (used[l]) { pos[s][l] = (v_t)nd.size(); nd.push_back(l); }
+                }
+                off[s + 1] = off[s] + (v_t)S.need[i][s].size();
+            }
+            (void)shard;
+            S.halo_remote[i] = merge_remote(blocks, i, std::max<v_t>(off[P], 1), [](v_t) { return true; },
+                                            [&](std::size_t s, v_t l) { return (v_t)(off[s] + pos[s][l]); });
+        });
+    }
+    void need_chunks() const { std::call_once(st_->chunks_once, [this] { build_chunks(); }); }
+    void need_halo() const { std::call_once(st_->halo_once, [this] { build_halo(); }); }
 
 public:
     dist_row_csr_matrix() = default;
@@ -157,71 +234,29 @@ public:
         const v_t rows = p[1] - p[0];                     // equal shards (N % P == 0, reference :428)
         std::size_t K = chunks ? chunks : mggcn_default_chunks(P);
         K = std::max<std::size_t>(1, std::min<std::size_t>(K, std::max<v_t>(rows, 1)));
-        for (std::size_t c = 0; c <= K; c++) chunk_bounds_.push_back((v_t)(c * (std::size_t)rows / K));
-        std::vector<v_t> piece_of(rows);
-        for (std::size_t c = 0; c < K; c++)
-            for (v_t l = chunk_bounds_[c]; l < chunk_bounds_[c + 1]; l++) piece_of[l] = (v_t)c;
-        for (std::size_t i = 0; i < P; i++) {
-            As.push_back(split_rows(A, p[i], p[i + 1], q));
-            const auto &blocks = As.back();
-            // (a) all-gather schedule: piece c gathers rows cb[c]..cb[c+1] of EVERY shard in rank order, so
-            //     entry (s, l) of piece c = piece_of[l] lands at column s * len_c + (l - cb[c])
-            chunks_.emplace_back();
-            for (std::size_t c = 0; c < K; c++) {
-                const v_t lo = chunk_bounds_[c], len = chunk_bounds_[c + 1] - lo;
-                std::vector<matrix_t> masked;                      // the blocks restricted to this piece's columns
-                for (std::size_t s = 0; s < P; s++) {
-                    if (s == i) { masked.emplace_back(std::vector<x_t>(rows + 1, 0), std::vector<v_t>{}, std::vector<r_t>{}, len); continue; }
-                    const auto &b = blocks[s];
-                    std::vector<x_t> ptr(rows + 1, 0);
-                    std::vector<v_t> idx;
-                    std::vector<r_t> dat;
-                    for (v_t r = 0; r < rows; r++) {
-                        for (auto e = b.begin(r); e < b.end(r); e++)
-                            if (piece_of[b.indices()[e]] == c) { idx.push_back(b.indices()[e] - lo); dat.push_back(b.data()[e]); }
-                        ptr[r + 1] = (x_t)idx.size();
-                    }
-                    masked.emplace_back(std::move(ptr), std::move(idx), std::move(dat), len);
-                }
-                chunks_.back().push_back(merge_remote(masked, i, (v_t)(P * len), [&](std::size_t s, v_t l) { return (v_t)(s * len + l); }));
-            }
-            // (b) halo schedule: distinct referenced rows per source shard, receive layout in source order
-            need_.emplace_back(P);
-            std::vector<v_t> off(P + 1, 0);
-            for (std::size_t s = 0; s < P; s++) {
-                if (s != i) {
-                    auto &nd = need_.back()[s];
-                    nd = blocks[s].indices();
-                    std::sort(nd.begin(), nd.end());
-                    nd.erase(std::unique(nd.begin(), nd.end()), nd.end());
-                }
-                off[s + 1] = off[s] + (v_t)need_.back()[s].size();
-            }
-            const auto &need_i = need_.back();
-            halo_remote_.push_back(merge_remote(blocks, i, std::max<v_t>(off[P], 1), [&](std::size_t s, v_t l) {
-                const auto &nd = need_i[s];
-                return (v_t)(off[s] + (std::lower_bound(nd.begin(), nd.end(), l) - nd.begin()));
-            }));
-        }
+        for (std::size_t c = 0; c <= K; c++) st_->chunk_bounds.push_back((v_t)(c * (std::size_t)rows / K));
+        st_->As.resize(P);
+        for_each_block(P, [&](std::size_t i) { st_->As[i] = split_rows(A, p[i], p[i + 1], q); });
     }
 
-    auto n() const { std::size_t N = 0; for (const auto &row : As) N += row[0].n(); return N; }
+    auto n() const { std::size_t N = 0; for (const auto &row : st_->As) N += row[0].n(); return N; }
     auto m() const { return M_; }
-    auto size() const { return As.size(); }
-    auto operator[](std::pair<std::size_t, std::size_t> ij) const { return As[ij.first][ij.second]; }
+    auto size() const { return st_->As.size(); }
+    auto operator[](std::pair<std::size_t, std::size_t> ij) const { return st_->As[ij.first][ij.second]; }
     const std::vector<v_t> &bounds() const { return p_; }
     // all-gather schedule
-    std::size_t chunks() const { return chunk_bounds_.size() - 1; }
-    const std::vector<v_t> &chunk_bounds() const { return chunk_bounds_; }
-    const matrix_t &remote_chunk(std::size_t i, std::size_t c) const { return chunks_[i][c]; }
+    std::size_t chunks() const { return st_->chunk_bounds.size() - 1; }
+    const std::vector<v_t> &chunk_bounds() const { return st_->chunk_bounds; }
+    const matrix_t &remote_chunk(std::size_t i, std::size_t c) const { need_chunks(); return st_->chunks[i][c]; }
     // halo schedule
-    const matrix_t &halo_remote(std::size_t i) const { return halo_remote_[i]; }
-    const std::vector<v_t> &halo_need(std::size_t i, std::size_t s) const { return need_[i][s]; }
+    const matrix_t &halo_remote(std::size_t i) const { need_halo(); return st_->halo_remote[i]; }
+    const std::vector<v_t> &halo_need(std::size_t i, std::size_t s) const { need_halo(); return st_->need[i][s]; }
     // rows moved per (receiver, source) pair: the matrix test/data/prep.py:237-244 prints for a partition
     std::vector<std::vector<std::size_t>> halo_volume() const {
+        need_halo();
         std::vector<std::vector<std::size_t>> V(size(), std::vector<std::size_t>(size(), 0));
         for (std::size_t i = 0; i < size(); i++)
-            for (std::size_t s = 0; s < size(); s++) V[i][s] = need_[i][s].size();
+            for (std::size_t s = 0; s < size(); s++) V[i][s] = st_->need[i][s].size();
         return V;
     }
 };

@@ -62,6 +62,18 @@ static void dump_dense(const std::filesystem::path &path, const dn_matrix<float>
     out.write(reinterpret_cast<const char *>(h.data()), (std::streamsize)(h.size() * sizeof(float)));
 }
 
+// MGGCN_TIMING=1: host seconds of every start-up stage on stderr ("[mggcn timing] <stage> <s>"), for the set-up figures
+// DESIGN.md quotes; off by default (the reference prints nothing there)
+struct stage_timer {
+    const bool on = std::getenv("MGGCN_TIMING") && std::string(std::getenv("MGGCN_TIMING")) != "0";
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    void operator()(const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (on) std::cerr << "[mggcn timing] " << what << ' ' << std::chrono::duration<double>(now - last).count() << std::endl;
+        last = now;
+    }
+};
+
 static bool env_is(const char *name, const char *value) {
     const char *s = std::getenv(name);
     return s && std::string(s) == value;
@@ -98,12 +110,15 @@ int main_(int argc, char **argv) {
         if ((int)mggcn_device_count() < (int)std::max<std::size_t>(P, 1) && !(oversubscribe && mggcn_device_count() > 0))
             throw arg_error("not enough GPUs visible for -P");
 
+        stage_timer stage;
         mggcn_set_device(0);
+        stage("device");
         csr_matrix<x_t, v_t, r_t> A(dir / "graph.bin");
         dn_matrix<r_t> X(dir / "features.bin");
         dn_matrix<std::int32_t> Y(dir / "labels.bin");
         dn_matrix<std::int32_t> S(dir / "sets.bin");               // loaded, never used (reference :85)
         (void)S;
+        stage("load-files");
         std::cerr << A.n() << ' ' << A.nnz() << std::endl;
         const auto labels = Y.to_host();
         const auto num_labels = 1 + *std::max_element(labels.begin(), labels.end());
@@ -134,6 +149,7 @@ int main_(int argc, char **argv) {
             auto ctx = context(0);
             gcn<x_t, v_t, r_t> G(A, sizes, false, fused);
             ctx.sync();
+            stage("model (normalize, transpose, layers)");
             ctx.record("training-start", 0);
             for (std::size_t e = 0; e < num_epochs; e++) {
                 if (const char *dd = std::getenv("MGGCN_DUMP_WEIGHTS")) {
@@ -150,6 +166,7 @@ int main_(int argc, char **argv) {
                 ctx.sync();
                 const auto duration = std::chrono::duration<double>{std::chrono::system_clock::now() - start}.count();
                 std::cerr << e << ' ' << loss << ' ' << acc << ' ' << duration << std::endl;
+                if (e == 0) stage("epoch 0 (SpMM plans built on first use)");
                 ctx.dump_timers(of, std::to_string(e) + "_0_");
             }
         } else if (row_partition) {
@@ -157,14 +174,18 @@ int main_(int argc, char **argv) {
             auto ctx = dist_context(P, overlap);
             std::vector<v_t> p(P + 1);
             for (std::size_t i = 1; i < p.size(); i++) p[i] = (v_t)(i * A.n() / P);
+            stage("dist_context");
             A.normalize(true);
             auto A_T = A.transpose();
+            stage("normalize + transpose");
             dist_row_dn_matrix<std::int32_t> Yd(ctx, Y);
             dist_row_csr_matrix<x_t, v_t, r_t> Ad(ctx, A, p, p);
             dist_row_csr_matrix<x_t, v_t, r_t> A_Td(ctx, A_T, p, p);
+            stage("block split (A, A_T)");
             dist_gcn<true, x_t, v_t, r_t> G(ctx, Ad, A_Td, sizes, false, fused, mode);
             dist_row_dn_matrix<r_t> Xd(ctx, X);
             ctx.sync();
+            stage("model + shards");
             ctx.record("training-start", 0);
             for (std::size_t e = 0; e < num_epochs; e++) {
                 const auto start = std::chrono::system_clock::now();
@@ -174,6 +195,7 @@ int main_(int argc, char **argv) {
                 ctx.sync();
                 const auto duration = std::chrono::duration<double>{std::chrono::system_clock::now() - start}.count();
                 std::cerr << e << ' ' << loss << ' ' << acc << ' ' << duration << "\n";
+                if (e == 0) stage("epoch 0 (exchange forms + SpMM plans built on first use)");
                 ctx.dump_timers(of, std::to_string(e) + "_");
             }
         }
