@@ -244,7 +244,7 @@ def test_c4_products_shape(pkg, ctx):
     rank_share_check(pkg, ctx, M, 8, 5, 4, d, seed=41)
 
 
-def test_c4_products_full_epoch_matches_oracle(pkg, oracle, ctx):
+def test_c4_products_full_epoch_matches_oracle(pkg, oracle, ctx, tmp_path):
     """BASELINE.json configs[3] as a PATH, not a product: one full training epoch (forward, loss, backward) of the
     128-128-128-128-48 GCN on the products-shaped graph (undirected like the OGB one: pattern A = A^T, rows sorted;
     n = 2 449 032, 126.2 M non-zeros; 47 classes padded to 48 as at P = 8, src/main.cpp:135) on one GPU -- row-split
@@ -273,7 +273,24 @@ def test_c4_products_full_epoch_matches_oracle(pkg, oracle, ctx):
     loss1, _ = G.train_step(ctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
     loss2, _ = G.train_step(ctx, Xd, Yd, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
     assert loss1 == pytest.approx(loss, rel=1e-6) and loss2 < loss1     # same forward again, then it trains
-    del G
+    del G, Xd, Yd
+    import torch
+    torch.cuda.empty_cache()
+    # ... and as BASELINE.json states it: `mg_gcn -P 8 -R 1` (src/main.cpp:134-170) on the same files -- the partition,
+    # the K-piece exchange, libmggcn_comm and the fused all-reduce at the products size, eight ranks wrapped over this
+    # box's one GPU (peer-copy transport).  47 classes are padded to 48 there: the same function as the model above.
+    import os, subprocess
+    d = tmp_path / "permuted" / "products"
+    pkg.datasets.write_dataset(str(d), ip, ix, dv, X, Y)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mg-gcn_amd", "bin", "mg_gcn")
+    r = subprocess.run([exe, "-P", "8", "-R", "1", "-E", "2", "train", str(d), "3", "128", "128", "128"], cwd=str(tmp_path),
+                       env=dict(os.environ, MGGCN_OVERSUBSCRIBE="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stderr.strip().splitlines()
+    assert lines[0] == "2449032 126200000" and lines[1] == "num_labels = 47" and lines[2] == "feature size = 128"
+    ep = [ln.split() for ln in lines[3:5]]
+    assert abs(float(ep[0][1]) - want_loss) <= TOL * abs(want_loss), (ep[0], want_loss)
+    assert float(ep[1][1]) < float(ep[0][1])
 
 
 def test_c5_papers100m_rank_share(pkg, ctx):
