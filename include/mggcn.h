@@ -105,6 +105,10 @@ void mggcn_memset_zero(void *dst, size_t bytes, mggcn_stream_t stream);
  *    of the matrix, 8 B per non-zero).  Pass NULL for both to skip it.
  * The arrays later passed to mggcn_spmm_csr_f32 with a plan must hold the matrix the
  * plan was built for (the sweep form reads its own copy).
+ * No input order is assumed: rows may or may not be sorted by column (heavy rows are cut into interleaved slices), and
+ * a vertex order with locality (an unpermuted community graph: most non-zeros near the diagonal) is detected at plan
+ * time -- the sweep form then works on a fixed pseudo-random relabelling of the columns and copies B into a plan-owned
+ * scratch in that order at the start of every call (the caller's B is never written).
  * Re-entrancy: every entry point of this header is enqueue-only and may be called from any stream, but a
  * PLAN owns mutable device scratch (partial-sum slots of sliced rows, the re-pitched copy of B of the narrow
  * form): one plan may be in flight on ONE stream at a time.  Calls on the same stream are ordered and safe;

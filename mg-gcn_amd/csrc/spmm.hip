@@ -268,10 +268,16 @@ struct mggcn_spmm_plan {
     // narrow form (d_hint <= 64): scratch for B re-pitched to 64-byte-multiple rows, n_cols x bpad_dp floats
     float *d_bpad = nullptr;
     uint32_t bpad_dp = 0;
+    // internal column permutation (vertex orders with locality, see mggcn_spmm_plan_create_for): row j of the permuted
+    // copy of B is row d_src_row[j] of the caller's B; d_bperm = scratch for that copy in the wide form (the narrow form
+    // folds the permutation into its re-pitch pass)
+    uint32_t *d_src_row = nullptr;
+    float *d_bperm = nullptr;
     // what the plan builder decided (mggcn_spmm_plan_describe)
     uint32_t d_hint = 0;
     int hot_columns = -1;          // -1: not measured (no sweep form considered)
     double hot_share = 0.0;        // share of the non-zeros in the 1 % most popular columns
+    double locality = 0.0;         // share of the non-zeros whose column lies in the same 1/32 of the index space as their row
     double mean_run = 0.0;         // mean (panel,row) run length the density gate saw
     double build_s = 0.0;          // host seconds spent in plan_create (sort + upload)
     uint64_t nnz = 0;
@@ -362,8 +368,18 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         if (n_cols >= 100 && host_indices) {
             std::vector<uint32_t> cc(n_cols, 0u);
             const uint64_t nz0 = host_indptr[0], nz1 = host_indptr[n_rows];
-            for (uint64_t e = nz0; e < nz1; e++)
-                if (host_indices[e] < n_cols) cc[host_indices[e]]++;
+            // ... and, in the same pass, how much of the matrix sits near its diagonal: a vertex order with locality
+            // (an unpermuted community graph) -- see the column permutation below
+            const uint32_t gr = std::max<uint32_t>(1u, (n_rows + 31) / 32), gc = std::max<uint32_t>(1u, (n_cols + 31) / 32);
+            uint64_t near = 0;
+            for (uint32_t r = 0; r < n_rows; r++) {
+                const uint32_t g = r / gr;
+                for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) {
+                    const uint32_t c = host_indices[e];
+                    if (c < n_cols) { cc[c]++; near += (c / gc == g); }
+                }
+            }
+            plan->locality = nz1 > nz0 ? (double)near / (double)(nz1 - nz0) : 0.0;
             const size_t top = std::max<size_t>(1, n_cols / 100);
             std::nth_element(cc.begin(), cc.begin() + top, cc.end(), std::greater<uint32_t>());
             uint64_t hot = 0;
@@ -389,6 +405,46 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         plan->mean_run = mean_run;
         const bool worth_it = total_nnz >= env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20) &&   // small graphs: row-split is fine
                               mean_run * 10.0 >= env_u32("MGGCN_SPMM_SWEEP_MIN_RUN_X10", 20u);
+        // Vertex orders with locality.  The sweep wants every wave of the chip to cross the column panels together, with
+        // about the same work in each -- true when a row's columns are spread over the index space (the randomly permuted
+        // datasets the reference trains on, test/data/prep.py:87-94).  On an UNPERMUTED community graph a row's entries
+        // sit in one panel, every 16-row task is sixteen spikes at sixteen different panels, the waves are never in the
+        // same place, and the L2 holds nothing: 4.29 ms for 87 M non-zeros against 2.35 for 115 M on the permuted graph
+        // (profiles/experiments/community_r03_*.log).  Detected (>= 8 % of the non-zeros within 1/32 of the diagonal; a
+        // permuted graph has 3 %, the same graph numbered by decreasing degree 11 %, 64 contiguous communities 85 %), the plan relabels the COLUMNS by a fixed pseudo-random permutation pi: the entry streams
+        // are built on pi(column), and every call first copies B into the plan's scratch in permuted row order (one
+        // streaming pass; the narrow form folds it into its re-pitch pass).  MGGCN_SPMM_PERMUTE_COLUMNS = 0 / 1 overrides.
+        std::vector<uint32_t> permuted_indices;
+        const uint32_t permute_knob = env_u32("MGGCN_SPMM_PERMUTE_COLUMNS", 2u);
+        if (worth_it && (permute_knob == 1u || (permute_knob == 2u && plan->locality >= 0.08)) && n_cols > 1) {
+            std::vector<uint32_t> pi(n_cols), src_row(n_cols);
+            for (uint32_t c = 0; c < n_cols; c++) pi[c] = c;
+            uint64_t x = 0x9E3779B97F4A7C15ull;                    // fixed-seed Fisher-Yates (splitmix64)
+            for (uint32_t c = n_cols - 1; c > 0; c--) {
+                x += 0x9E3779B97F4A7C15ull;
+                uint64_t z = x;
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                z ^= z >> 31;
+                std::swap(pi[c], pi[(uint32_t)(z % (c + 1))]);
+            }
+            for (uint32_t c = 0; c < n_cols; c++) src_row[pi[c]] = c;
+            const uint64_t nz0 = host_indptr[0], nz1 = host_indptr[n_rows];
+            permuted_indices.resize(nz1);                           // indexed like host_indices (offset nz0 kept)
+            for (uint64_t e = nz0; e < nz1; e++) {
+                MGGCN_REQUIRE(host_indices[e] < n_cols, "column index out of range");
+                permuted_indices[e] = pi[host_indices[e]];
+            }
+            host_indices = permuted_indices.data();
+            MGGCN_CHECK_HIP(hipMalloc(&plan->d_src_row, (size_t)n_cols * sizeof(uint32_t)));
+            MGGCN_CHECK_HIP(hipMemcpy(plan->d_src_row, src_row.data(), (size_t)n_cols * sizeof(uint32_t), hipMemcpyHostToDevice));
+            plan->bytes += (size_t)n_cols * sizeof(uint32_t);
+            {   // scratch for the permuted copy at any width <= max_d (a narrow plan also serves wide calls)
+                const size_t bb = (size_t)n_cols * ((max_d + 3) / 4 * 4) * sizeof(float);
+                MGGCN_CHECK_HIP(hipMalloc(&plan->d_bperm, bb));
+                plan->bytes += bb;
+            }
+        }
         if (!worth_it) {
             // nothing
         } else if (S <= 1) {
@@ -457,10 +513,10 @@ MGGCN_API int mggcn_spmm_plan_describe(const mggcn_spmm_plan *plan, char *out, s
         const int k = std::snprintf(out + at, cap - at, fmt, a...);
         if (k > 0) at = std::min(cap - 1, at + (size_t)k);
     };
-    put("rows=%u cols=%u nnz=%llu max_d=%u d_hint=%u form=%s hot_share=%.3f hot_columns=%d mean_run=%.2f slices=%zu bytes=%zu build_s=%.3f",
+    put("rows=%u cols=%u nnz=%llu max_d=%u d_hint=%u form=%s hot_share=%.3f hot_columns=%d locality=%.3f permuted=%d mean_run=%.2f slices=%zu bytes=%zu build_s=%.3f",
         plan->n_rows, plan->n_cols, (unsigned long long)plan->nnz, plan->max_d, plan->d_hint,
         plan->sweeps.empty() ? "rowsplit" : (plan->d_bpad ? "sweep-narrow" : "sweep"), plan->hot_share, plan->hot_columns,
-        plan->mean_run, plan->sweeps.size(), mggcn_spmm_plan_bytes(plan), plan->build_s);
+        plan->locality, plan->d_src_row ? 1 : 0, plan->mean_run, plan->sweeps.size(), mggcn_spmm_plan_bytes(plan), plan->build_s);
     if (plan->sweeps.empty()) put(" items=%u split_rows=%u", plan->n_items, plan->n_split_rows);
     for (auto *sp : plan->sweeps) {
         char one[256];
@@ -477,6 +533,8 @@ MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {
     if (plan->d_split) MGGCN_CHECK_HIP(hipFree(plan->d_split));
     if (plan->d_partial) MGGCN_CHECK_HIP(hipFree(plan->d_partial));
     if (plan->d_bpad) MGGCN_CHECK_HIP(hipFree(plan->d_bpad));
+    if (plan->d_src_row) MGGCN_CHECK_HIP(hipFree(plan->d_src_row));
+    if (plan->d_bperm) MGGCN_CHECK_HIP(hipFree(plan->d_bperm));
     delete plan;
 }
 
@@ -560,10 +618,16 @@ MGGCN_API void mggcn_spmm_csr_f32(mggcn_stream_t stream, const mggcn_spmm_plan *
         if (!plan->sweeps.empty() && sweep_supports(plan->sweeps[0], d, ldb, ldc, B, C)) {
             const size_t S = plan->sweeps.size();
             const uint32_t dp = (d + 15) / 16 * 16;
-            if (plan->d_bpad && dp <= plan->bpad_dp && sweep_wants_repack(plan->sweeps[0], d, ldb, B)) {
-                sweep_repack(st, B, ldb, n_cols, d, plan->d_bpad, dp);     // 64-byte pitched copy of B
+            if (plan->d_bpad && dp <= plan->bpad_dp && (plan->d_src_row || sweep_wants_repack(plan->sweeps[0], d, ldb, B))) {
+                sweep_repack(st, B, ldb, n_cols, d, plan->d_bpad, dp, plan->d_src_row);     // 64-byte pitched (and permuted) copy of B
                 B = plan->d_bpad;
                 ldb = dp;
+            } else if (plan->d_src_row) {                                  // wide form on a permuted plan: B' = B[src_row]
+                const uint32_t d4 = (d + 3) / 4 * 4;
+                MGGCN_REQUIRE(plan->d_bperm != nullptr && d4 <= (plan->max_d + 3) / 4 * 4, "feature width exceeds the permuted plan's scratch");
+                sweep_repack(st, B, ldb, n_cols, d, plan->d_bperm, d4, plan->d_src_row);
+                B = plan->d_bperm;
+                ldb = d4;
             }
             for (size_t k = 0; k < S; k++)       // beta only once, the fused activation only on the full sum
                 sweep_launch(st, plan->sweeps[k], B, ldb, C, ldc, d, alpha, k == 0 ? beta : 1.f,

@@ -17,7 +17,9 @@ uint32_t sweep_panel_rows(uint32_t d_hint, bool hot_columns = true);
 uint32_t sweep_lanes_per_entry(uint32_t d_hint);   // 4 / 8 / 12 / 16 float4 lanes per gathered row
 // narrow form only: true when B has to be re-pitched to 16-byte rows before sweep_launch
 bool sweep_wants_repack(const SweepPlan *p, uint32_t d, size_t ldb, const void *B);
-void sweep_repack(hipStream_t st, const float *B, size_t ldb, uint32_t n_cols, uint32_t d, float *out, uint32_t dp);
+// copy of B at pitch dp (multiple of 4 floats); src_row != nullptr: row r of the copy = row src_row[r] of B
+void sweep_repack(hipStream_t st, const float *B, size_t ldb, uint32_t n_cols, uint32_t d, float *out, uint32_t dp,
+                  const uint32_t *src_row = nullptr);
 void sweep_plan_destroy(SweepPlan *p);
 size_t sweep_plan_bytes(const SweepPlan *p);
 int sweep_plan_describe(const SweepPlan *p, char *out, size_t cap);   // one line: tasks, rounds, panel rows, lpe, entries

@@ -514,13 +514,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
 // -> index-mode fold); they are added once per task.  1.63 ms.  (Tried and dropped: 8-byte lanes
 // at 4-byte alignment, two rows per instruction -- no faster than one row per instruction.)
 // ---------------------------------------------------------------------------------------
+// src_row (optional): row r of the copy is row src_row[r] of B -- the plan's internal column permutation (spmm.hip)
 __global__ __launch_bounds__(256) void sweep_repack_kernel(const float *__restrict__ B, size_t ldb, uint32_t n,
-                                                           uint32_t d, float *__restrict__ out, uint32_t dp) {
+                                                           uint32_t d, float *__restrict__ out, uint32_t dp,
+                                                           const uint32_t *__restrict__ src_row) {
     const uint32_t q4 = dp / 4;
     const size_t total = (size_t)n * q4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t r = (uint32_t)(i / q4), c = (uint32_t)(i % q4) * 4;
-        const float *src = B + (size_t)r * ldb + c;
+        const float *src = B + (size_t)(src_row ? src_row[r] : r) * ldb + c;
         float4 v;
         v.x = c + 0 < d ? src[0] : 0.f;
         v.y = c + 1 < d ? src[1] : 0.f;
@@ -1127,10 +1129,11 @@ bool sweep_wants_repack(const SweepPlan *p, uint32_t d, size_t ldb, const void *
     return !(ldb % 16 == 0 && (reinterpret_cast<uintptr_t>(B) & 63u) == 0);
 }
 
-void sweep_repack(hipStream_t st, const float *B, size_t ldb, uint32_t n_cols, uint32_t d, float *out, uint32_t dp) {
+void sweep_repack(hipStream_t st, const float *B, size_t ldb, uint32_t n_cols, uint32_t d, float *out, uint32_t dp,
+                  const uint32_t *src_row) {
     const size_t total = (size_t)n_cols * (dp / 4);
     const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, (size_t)kNumCU * 16);
-    hipLaunchKernelGGL(sweep_repack_kernel, dim3(std::max(grid, 1u)), dim3(256), 0, st, B, ldb, n_cols, d, out, dp);
+    hipLaunchKernelGGL(sweep_repack_kernel, dim3(std::max(grid, 1u)), dim3(256), 0, st, B, ldb, n_cols, d, out, dp, src_row);
     MGGCN_CHECK_LAUNCH();
 }
 

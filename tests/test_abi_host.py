@@ -365,3 +365,16 @@ def test_public_headers_are_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
                         "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_traffic_counters_belong_to_the_kernels_in_the_tree():
+    """bench.py replays `roofline.traffic` from profiles/spmm_hbm_traffic.json (separate rocprofv3 --pmc passes of an
+    earlier run).  The file carries a content hash of csrc/spmm*.hip at collection time: after a kernel change the
+    counters have to be collected again (profiles/collect.sh + summarize.py) -- this test is what notices."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    j = json.load(open(os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")))
+    assert j.get("kernel_source_sha") == bench.spmm_kernel_sha(), \
+        "profiles/spmm_hbm_traffic.json is older than csrc/spmm*.hip: run profiles/collect.sh + summarize.py again"
+    assert os.path.exists(os.path.join(ROOT, j["source"]))

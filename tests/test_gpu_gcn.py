@@ -339,11 +339,14 @@ def test_residual_layer_matches_oracle(pkg, oracle, ctx, fused, sizes):
         ctx.sync()
 
 
-@pytest.mark.parametrize("fused", [False, True])
-def test_hoisted_first_aggregation_matches_the_reference_epoch(pkg, oracle, ctx, fused):
+@pytest.mark.parametrize("fused,sweep", [(False, False), (True, False), (True, True)])
+def test_hoisted_first_aggregation_matches_the_reference_epoch(pkg, oracle, ctx, fused, sweep, monkeypatch):
     """gcn(hoist_first_aggregation=True): layer 0's loop-invariant A_fwd . X is computed once, the epoch runs one SpMM
     fewer ((A_fwd X) W + 1 b^T = A_fwd (X W + 1 b^T) since A_fwd 1 = 1).  Optional mode, never the headline: it must
     give the unhoisted model's and the oracle's loss and gradients at 1e-4, on the Reddit layer stack."""
+    if sweep:        # the form the full-size graph gets: the one-off d = 608 SpMM walks the row in 128-column passes
+        monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_NNZ", "0")
+        monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS", "256")
     sizes = [608, 128, 128, 128, 41]
     n = 2048
     ip, ix, dv = _graph(pkg, n, n * 24, 1200, seed=77)
@@ -359,6 +362,7 @@ def test_hoisted_first_aggregation_matches_the_reference_epoch(pkg, oracle, ctx,
         G = pkg.gcn(pkg.csr_matrix(ip, ix, dv.copy(), n), sizes, fused=fused, hoist_first_aggregation=hoist)
         assert G.layers()[0].hoist_input is hoist
         loss, acc = G.train_forward(ctx, Xd, Yd)
+        assert (G.layers()[0].A.ext_buffer.num_sweep_tasks() > 0) == sweep
         G.backward(ctx)
         ctx.sync()
         got[hoist] = (loss, acc, [(l.GW().numpy().copy(), l.Gb().numpy().copy()) for l in G.layers()])

@@ -317,10 +317,12 @@ def test_adam_fused_equals_chain_equals_oracle(pkg, oracle, ctx):
 
 
 # ---- column-panel sweep form of the SpMM (spmm_sweep.hip) ---------------------------------
-@pytest.fixture
-def force_sweep(monkeypatch):
+@pytest.fixture(params=[False, True], ids=["columns-as-given", "columns-permuted"])
+def force_sweep(monkeypatch, request):
     """Small test matrices would fall back to the row-split kernels: force the sweep form
-    and a tiny panel so that the (panel, row) ordering of the entry streams is exercised."""
+    and a tiny panel so that the (panel, row) ordering of the entry streams is exercised.
+    Second variant: the plan's internal column permutation (what a vertex order with locality triggers) forced on."""
+    monkeypatch.setenv("MGGCN_SPMM_PERMUTE_COLUMNS", "1" if request.param else "0")
     monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_NNZ", "1")
     monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS", "64")
     monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS_NARROW", "96")
@@ -394,6 +396,34 @@ def test_sweep_plan_hint_only_picks_the_fast_form(pkg, oracle, ctx, force_sweep,
             want = oracle.leaky_relu_forward(want)
         assert rowwise_relerr(Cd.numpy(), want) <= TOL, (d_hint, d, alpha, beta)
         np.testing.assert_array_equal(Bd.numpy(), B)          # the re-pitch never writes the caller's B
+
+
+def test_vertex_order_with_locality_gets_its_columns_permuted(pkg, oracle, ctx, monkeypatch):
+    """A banded matrix (every row's columns within +-40 of the diagonal: an unpermuted community graph in miniature)
+    is detected at plan time (`locality` in mggcn_spmm_plan_describe) and the plan relabels its columns; a matrix with
+    scattered columns is left alone.  Same results either way."""
+    monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_NNZ", "1")
+    monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS", "128")
+    monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_RUN_X10", "0")
+    monkeypatch.delenv("MGGCN_SPMM_PERMUTE_COLUMNS", raising=False)
+    monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
+    n, deg = 6000, 24
+    rng = np.random.default_rng(9)
+    rows = np.repeat(np.arange(n), deg)
+    banded = np.clip(rows + rng.integers(-40, 41, size=n * deg), 0, n - 1)
+    scattered = rng.integers(0, n, size=n * deg)
+    for cols, want_perm in ((banded, True), (scattered, False)):
+        ip = (np.arange(n + 1) * deg).astype(np.uint32)
+        ix = cols.astype(np.uint32)
+        dv = rng.standard_normal(n * deg).astype(np.float32)
+        A, Ao = _csr(pkg, oracle, ip, ix, dv, n)
+        for d in (128, 41):
+            B = rng.standard_normal((n, d), dtype=np.float32)
+            C0 = rng.standard_normal((n, d), dtype=np.float32)
+            got, buf = _run_spmm(pkg, ctx, A, B, C0, 0.5, 2.0)
+            assert buf.num_sweep_tasks() > 0
+            assert ("permuted=1" in buf.describe()) == want_perm, buf.describe()
+            assert rowwise_relerr(got, oracle.spmm(Ao, B, C0.copy(), 0.5, 2.0, f64acc=True)) <= TOL
 
 
 def test_sweep_equals_rowsplit_on_a_big_graph(pkg, ctx, monkeypatch):
