@@ -10,7 +10,7 @@
       loading only its rows of the files (dist.load_rank_local), K-piece all-gather schedule.
 
 Both Reddit stand-ins (tests/conftest.py): the SURVEY.md 8(d) one and the symmetric one.  Epoch-0 loss against
-the CPU oracle (fp32 restatement and exact-accumulation twin) at 1e-4; for P > 1 the oracle runs with the class count
+the CPU oracle (exact-accumulation twin, pinned in tests/test_oracle_kat.py) at 1e-4; for P > 1 the oracle runs with the class count
 padded to a multiple of P (src/main.cpp:135) -- the row-partitioned model computes the same function, regrouped.
 The CLI's own per-epoch seconds are printed (pytest -s) and bounded loosely; bench.py reports them as `cli_epoch_ms`."""
 import os
@@ -57,11 +57,12 @@ def _check_header(stderr):
 
 
 def _check_loss(got, oracle, data, classes):
+    """against the exact-accumulation twin (the fp32 restatement's own distance to it at this size is measured in
+    tests/test_gpu_configs.py::test_c2_full_epoch_matches_oracle; one oracle epoch is ~6 s of host time)"""
     from conftest import reddit_oracle_epoch
-    for f64 in (True, False):
-        want = reddit_oracle_epoch(oracle, data, classes, f64)
-        assert abs(got[1] - want["loss"]) <= TOL * abs(want["loss"]), (data["kind"], classes, f64, got, want["loss"])
-        assert abs(got[2] - want["acc"]) <= 8.0 / data["n"], (got, want["acc"])
+    want = reddit_oracle_epoch(oracle, data, classes, True)
+    assert abs(got[1] - want["loss"]) <= TOL * abs(want["loss"]), (data["kind"], classes, got, want["loss"])
+    assert abs(got[2] - want["acc"]) <= 8.0 / data["n"], (got, want["acc"])
 
 
 def test_cli_c2_full_reddit(oracle, reddit_any, reddit_dirs):
