@@ -137,12 +137,18 @@ def main():
     # through gloo (RCCL refuses two ranks on one device).  Exercises this file's N > 1 code path;
     # its numbers mean nothing.
     rehearsal = os.environ.get("MGGCN_BENCH_REHEARSAL", "0") == "1"
+    # MGGCN_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, rank-local load, dist_gcn, comm report) with ONE
+    # rank -- the only way to run that path over the real RCCL backend on a one-GPU box (tests/test_gpu_bench.py)
+    multi = P > 1 or os.environ.get("MGGCN_BENCH_FORCE_DIST", "0") == "1"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if P > 1:
+    if multi:
         import torch.distributed as dist
+        if P == 1 and "RANK" not in os.environ:                 # forced single-rank run without a launcher
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                              MASTER_PORT=os.environ.get("MASTER_PORT", "29571"))
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -157,14 +163,14 @@ def main():
             return pkg.datasets.synth_products_like(args.scale, seed=5, symmetric=True)      # OGB's graph is undirected
         return pkg.datasets.synth_reddit_like(args.scale, seed=1, symmetric=symmetric)
     wl_name = {"reddit_like": "reddit_like_3x128_gcn", "products_like": "products_like_3x128_gcn"}[args.workload]
-    if P == 1:
+    if not multi:
         (indptr, indices, data), X, Y = make_workload(args.symmetric)
         n, nnz = int(indptr.shape[0] - 1), int(indptr[-1])
         num_labels = 1 + int(Y.max())
         sizes = [X.shape[1]] + list(args.hidden) + [num_labels]
         A = pkg.csr_matrix(indptr, indices, data, n)
 
-    if P == 1:
+    if not multi:
         ctx = pkg.context(local_rank)
         G = pkg.gcn(A, sizes, fused=fused)                   # normalises + transposes (gcn.hpp:946-948)
         Xd, Yd = pkg.dn_matrix.from_numpy(X), pkg.dn_matrix.from_numpy(Y)
@@ -219,7 +225,7 @@ def main():
     narrow_timers = timers_by_width.get(d_narrow, []) if d_narrow != d_main else []
 
     def barrier():
-        if P > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -236,7 +242,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     ms = (t1 - t0) * 1000.0 / max(args.steps, 1)
-    if P > 1:
+    if multi:
         t = torch.tensor([ms], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
@@ -252,7 +258,7 @@ def main():
         ach = b_alg / (avg * 1e-3) / 1e9
         traffic, src, sha_ok = None, None, None
         tf = os.path.join(ROOT, "profiles", "spmm_hbm_traffic.json")     # written from separate --pmc passes
-        if P == 1 and os.path.exists(tf) and args.workload == "reddit_like" and args.scale == 1.0:   # counters of THAT shape
+        if not multi and os.path.exists(tf) and args.workload == "reddit_like" and args.scale == 1.0:   # counters of THAT shape
             try:
                 j = json.load(open(tf))
                 traffic = j.get(traffic_key, j.get("bytes_per_launch") if traffic_key == "bytes_per_call" else None)
@@ -278,7 +284,7 @@ def main():
     def launches(d):
         """average kernel launches of one SpMM call at width d over the calls of an epoch (forward and backward
         matrices are cut differently); single GPU only"""
-        if P != 1:
+        if multi:
             return None
         per = []
         for layer in G.layers():
@@ -297,16 +303,16 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": (wl_name if args.scale == 1.0 else f"{args.workload}_scale_{args.scale}") + ("_symmetric" if args.symmetric else ""),
                    "n": n, "nnz": nnz, "sizes": sizes, "spmm_per_epoch": 2 * nl - 1,
-                   "parallelism": f"rows{P}" + ("" if P == 1 else f"-{args.mode}"), "fused": fused},
+                   "parallelism": f"rows{P}" + (f"-{args.mode}" if multi else ""), "fused": fused},
         "roofline": spmm_roofline(spmm_ms, d_main, launches(d_main), "bytes_per_call"),
         "roofline_narrow": spmm_roofline(narrow_ms, d_narrow, launches(d_narrow), "bytes_per_call_narrow") if narrow_timers else None,
         "loss_first_last": [round(float(losses[0]), 5), round(float(losses[-1]), 5)] if losses else None,
         "setup_s": round(t_gen, 1),
     }
 
-    if P > 1:
+    if multi:
         out["comm"] = comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers, args)
-    if rank == 0 and P == 1 and not args.no_extras:
+    if rank == 0 and not multi and not args.no_extras:
         # (1) the reference's own interface on the same workload: never the headline (it synchronises inside the loss
         #     like the reference, src/gcn.hpp:816; `value` goes through gcn.train_step with one sync per epoch)
         cli = run_cli_epochs(pkg, indptr, indices, data, X, Y, args.hidden)
@@ -349,13 +355,13 @@ def main():
             out["symmetric_spmm_ms_per_call"] = round(float(np.mean(per2)), 4) if per2 and per2[0] else None
             out["symmetric_setup_s"] = round(time.time() - t_sym - (time.perf_counter() - t2), 1)
             del G2, X2d, Y2d, ip2, ix2, dv2, X2, Y2
-    if rank == 0 and P == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg, indptr, indices, data, n, X, Y, sizes, d_main, args.workload)
         if args.warmup + args.steps > 0 and "loss" in out["cpu_baseline"]:
             out["cpu_baseline"]["loss_matches_gpu_first"] = bool(
                 abs(out["cpu_baseline"]["loss"] - losses[0]) <= 1e-4 * abs(out["cpu_baseline"]["loss"]))
 
-    if P > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -369,7 +375,7 @@ def comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers,
     time of its collectives (`exchange_ms`), the time the compute stream stalled waiting for pieces (`exposed_ms`)
     and overlap_frac = 1 - exposed / exchange.  Reference events: src/cuda_utils.hpp:61-89."""
     prop = torch.cuda.get_device_properties(local_rank)
-    me = {"rank": dctx.rank, "device": local_rank, "name": prop.name,
+    me = {"rank": dctx.rank, "device": local_rank, "name": prop.name, "arch": getattr(prop, "gcnArchName", None),
           "pci_bus_id": getattr(prop, "pci_bus_id", None), "uuid": str(getattr(prop, "uuid", ""))[:13]}
     devices = [None] * dctx.P
     dist.all_gather_object(devices, me)

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import __graft_entry__ as g
 pkg = g.load_package()
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
-(ip, ix, dv), _, _ = pkg.datasets.synth_reddit_like(1.0, seed=1)
+(ip, ix, dv), _, _ = pkg.datasets.synth_reddit_like(1.0, seed=1, symmetric=os.environ.get('SPMM_AB_SYMMETRIC', '0') == '1')
 n = ip.shape[0] - 1
 A = pkg.csr_matrix(ip, ix, dv, n); A.normalize(True)
 A_T = A.transpose()

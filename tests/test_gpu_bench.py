@@ -57,3 +57,25 @@ def test_bench_multi_rank_rehearsal_prints_one_json_line():
     assert [d["rank"] for d in comm["devices"]] == [0, 1] and all("name" in d and "device" in d for d in comm["devices"])
     assert comm["mode"] == "allgather" and comm["overlap"] is True and "rccl_version" in comm
     assert comm["exchange_ms"] > 0 and comm["exposed_ms"] >= 0 and comm["overlap_frac"] is not None
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_over_rccl_with_one_rank():
+    """The N > 1 code path of bench.py -- process group over the REAL backend (nccl = RCCL, device_id), rank-local
+    dataset load through device-staged host collectives, dist_gcn with the K-piece all-gather on ProcessGroupNCCL work
+    handles, the comm report (all_gather_object, RCCL version, the exchange-event pass) -- with the one rank a one-GPU
+    box allows (MGGCN_BENCH_FORCE_DIST=1).  What it cannot show is a second rank; what it does show is that nothing on
+    that path is gloo-only."""
+    env = dict(os.environ, MGGCN_BENCH_FORCE_DIST="1", MASTER_PORT="29549")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--scale", "0.05"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _one_json_line(r.stdout)
+    assert REQUIRED <= set(out) and out["n_gpus"] == 1 and out["config"]["parallelism"] == "rows1-allgather"
+    comm = out["comm"]
+    assert comm["backend"] == "nccl" and comm["world_size"] == 1 and comm["rehearsal_gloo_on_one_gpu"] is False
+    assert comm["rccl_version"] and comm["devices"][0]["device"] == 0 and "gfx950" in comm["devices"][0]["arch"]
+    assert comm["exchange_ms"] >= 0 and comm["exposed_ms"] >= 0
+    assert out["loss_first_last"][1] < out["loss_first_last"][0]
