@@ -28,6 +28,7 @@
 #include <functional>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -254,6 +255,32 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
 
 }  // namespace
 
+namespace {
+// host passes of the plan builder over the rows of A, cut into ranges of about equal non-zeros, one std::thread each
+// (matrices below 2^22 non-zeros: the calling thread alone).  fn(thread, row_begin, row_end).
+template <typename F>
+void plan_rows_parallel(uint32_t n_rows, const uint32_t *indptr, F &&fn, unsigned *threads_out = nullptr) {
+    const uint64_t nnz = n_rows ? (uint64_t)indptr[n_rows] - indptr[0] : 0;
+    unsigned T = 1;
+    if (nnz > (1u << 22)) {
+        T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        if (const char *s = std::getenv("MGGCN_HOST_THREADS")) T = std::max(1u, std::min(64u, (unsigned)std::strtoul(s, nullptr, 10)));
+    }
+    if (threads_out) { *threads_out = T; return; }
+    std::vector<uint32_t> cut(T + 1, n_rows);
+    cut[0] = 0;
+    for (unsigned t = 1; t < T; t++) {
+        const uint64_t target = indptr[0] + nnz * t / T;
+        cut[t] = (uint32_t)(std::lower_bound(indptr, indptr + n_rows, (uint32_t)target) - indptr);
+        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    }
+    if (T == 1) { fn(0u, 0u, n_rows); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++) th.emplace_back(fn, t, cut[t], cut[t + 1]);
+    for (auto &x : th) x.join();
+}
+}  // namespace
+
 struct mggcn_spmm_plan {
     uint32_t n_rows = 0, n_cols = 0, max_d = 0;
     uint32_t n_items = 0, n_split_rows = 0, n_slots = 0;
@@ -366,18 +393,31 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         // that sit in the 1 % most popular columns.
         bool hot_columns = true;
         if (n_cols >= 100 && host_indices) {
-            std::vector<uint32_t> cc(n_cols, 0u);
             const uint64_t nz0 = host_indptr[0], nz1 = host_indptr[n_rows];
             // ... and, in the same pass, how much of the matrix sits near its diagonal: a vertex order with locality
             // (an unpermuted community graph) -- see the column permutation below
             const uint32_t gr = std::max<uint32_t>(1u, (n_rows + 31) / 32), gc = std::max<uint32_t>(1u, (n_cols + 31) / 32);
-            uint64_t near = 0;
-            for (uint32_t r = 0; r < n_rows; r++) {
-                const uint32_t g = r / gr;
-                for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) {
-                    const uint32_t c = host_indices[e];
-                    if (c < n_cols) { cc[c]++; near += (c / gc == g); }
+            unsigned T = 1;
+            plan_rows_parallel(n_rows, host_indptr, [](unsigned, uint32_t, uint32_t) {}, &T);
+            std::vector<std::vector<uint32_t>> ccs(T, std::vector<uint32_t>(n_cols, 0u));
+            std::vector<uint64_t> nears(T, 0);
+            plan_rows_parallel(n_rows, host_indptr, [&](unsigned t, uint32_t r0, uint32_t r1) {
+                uint32_t *cnt = ccs[t].data();
+                uint64_t near_t = 0;
+                for (uint32_t r = r0; r < r1; r++) {
+                    const uint32_t g = r / gr;
+                    for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) {
+                        const uint32_t c = host_indices[e];
+                        if (c < n_cols) { cnt[c]++; near_t += (c / gc == g); }
+                    }
                 }
+                nears[t] = near_t;
+            });
+            std::vector<uint32_t> &cc = ccs[0];
+            uint64_t near = nears[0];
+            for (unsigned t = 1; t < T; t++) {
+                near += nears[t];
+                for (uint32_t c = 0; c < n_cols; c++) cc[c] += ccs[t][c];
             }
             plan->locality = nz1 > nz0 ? (double)near / (double)(nz1 - nz0) : 0.0;
             const size_t top = std::max<size_t>(1, n_cols / 100);
@@ -431,9 +471,14 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
             for (uint32_t c = 0; c < n_cols; c++) src_row[pi[c]] = c;
             const uint64_t nz0 = host_indptr[0], nz1 = host_indptr[n_rows];
             permuted_indices.resize(nz1);                           // indexed like host_indices (offset nz0 kept)
-            for (uint64_t e = nz0; e < nz1; e++) {
-                MGGCN_REQUIRE(host_indices[e] < n_cols, "column index out of range");
-                permuted_indices[e] = pi[host_indices[e]];
+            {
+                const uint32_t *src = host_indices;
+                plan_rows_parallel(n_rows, host_indptr, [&](unsigned, uint32_t r0, uint32_t r1) {
+                    for (uint64_t e = host_indptr[r0]; e < host_indptr[r1]; e++) {
+                        MGGCN_REQUIRE(src[e] < n_cols, "column index out of range");
+                        permuted_indices[e] = pi[src[e]];
+                    }
+                });
             }
             host_indices = permuted_indices.data();
             MGGCN_CHECK_HIP(hipMalloc(&plan->d_src_row, (size_t)n_cols * sizeof(uint32_t)));
@@ -454,8 +499,10 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
             // bucket the non-zeros by column slice: two passes over A whatever the slice count
             const uint32_t width = (n_cols + S - 1) / S;
             std::vector<std::vector<uint32_t>> ips(S, std::vector<uint32_t>((size_t)n_rows + 1, 0u));
-            for (uint32_t r = 0; r < n_rows; r++)
-                for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) ips[host_indices[e] / width][r + 1]++;
+            plan_rows_parallel(n_rows, host_indptr, [&](unsigned, uint32_t r0, uint32_t r1) {       // per-row counts: no sharing
+                for (uint32_t r = r0; r < r1; r++)
+                    for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) ips[host_indices[e] / width][r + 1]++;
+            });
             std::vector<std::vector<uint32_t>> ixs(S);
             std::vector<std::vector<float>> vvs(S);
             for (uint32_t k = 0; k < S; k++) {
@@ -463,14 +510,18 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
                 ixs[k].resize(ips[k][n_rows]);
                 vvs[k].resize(ips[k][n_rows]);
             }
-            std::vector<uint32_t> pos(S, 0u);          // rows are visited in order: one cursor per slice
-            for (uint32_t r = 0; r < n_rows; r++)
-                for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) {
-                    const uint32_t k = host_indices[e] / width;
-                    ixs[k][pos[k]] = host_indices[e];
-                    vvs[k][pos[k]] = host_values[e];
-                    pos[k]++;
+            plan_rows_parallel(n_rows, host_indptr, [&](unsigned, uint32_t r0, uint32_t r1) {       // every row knows its offsets
+                std::vector<uint32_t> pos(S);
+                for (uint32_t r = r0; r < r1; r++) {
+                    for (uint32_t k = 0; k < S; k++) pos[k] = ips[k][r];
+                    for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) {
+                        const uint32_t k = host_indices[e] / width;
+                        ixs[k][pos[k]] = host_indices[e];
+                        vvs[k][pos[k]] = host_values[e];
+                        pos[k]++;
+                    }
                 }
+            });
             bool ok = true;
             for (uint32_t k = 0; k < S && ok; k++) {
                 if (ixs[k].empty()) continue;            // e.g. a rank's own column range in its "remote" matrix

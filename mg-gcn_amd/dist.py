@@ -977,8 +977,20 @@ class dist_gcn:
                                                self.bcast_buffer, self.bcast_buffer2, fused, mode))
         link_fused_backward(self.layers_, fused)
         self.fused, self._adam = fused, None
+        # this rank's SpMM plans, built side by side before the first epoch (ops.prebuild_plans) instead of one by one
+        # inside it: the diagonal block and the pieces of the schedule that runs, both matrices, both widths
+        self._plan_wants = []
+        for i in range(1, len(sizes)):
+            w = min(sizes[i - 1], sizes[i])
+            for M in ([A_T] if i == 1 else [A_T, A]):               # layers get (A_T, A); first layer: no backward SpMM
+                parts = list(M.blocks) if mode == "rounds" else \
+                    [M.diag] + (list(M.remote_chunks) if mode == "allgather" and P > 1 else [])
+                self._plan_wants += [(blk, max(w, 128), w) for blk in parts]
 
     def __call__(self, dctx, H):
+        if self._plan_wants:
+            ops.prebuild_plans(dctx.ctx, self._plan_wants)
+            self._plan_wants = []
         for layer in self.layers_:
             H = layer(dctx, H)
         return H

@@ -433,6 +433,12 @@ class gcn:
         link_fused_backward(self.layers_, fused)
         self._adam = None
         self.set_hoist_first_aggregation(hoist_first_aggregation)
+        self._plan_wants = []                        # (matrix, max_d, width): built side by side on first use (prebuild_plans)
+        for i in range(1, len(sizes)):
+            w = min(sizes[i - 1], sizes[i])
+            self._plan_wants.append((A_T, max(w, 128), w))           # forward multiplies by A_T (gcn.hpp:954)
+            if i != 1:
+                self._plan_wants.append((A, max(w, 128), w))         # the first layer's backward SpMM is skipped
         if weights is not None:                     # test constructor, gcn.hpp:957-963
             assert len(weights) == len(self.layers_)
             for layer, (W, b) in zip(self.layers_, weights):
@@ -449,6 +455,9 @@ class gcn:
             l0._AX = l0._AX_key = None
 
     def __call__(self, ctx: context, H: dn_matrix) -> dn_matrix:
+        if self._plan_wants:                          # first call: the context (device) is known now
+            ops.prebuild_plans(ctx, self._plan_wants)
+            self._plan_wants = []
         for layer in self.layers_:
             H = layer(ctx, H)
         return H

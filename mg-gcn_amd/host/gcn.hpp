@@ -681,6 +681,14 @@ public:
                                  i != 1, HW_buffer, fused);
         link_fused_backward(layers_, fused);
         fused_ = fused;
+        // the SpMM plans of the model, built side by side now instead of one by one inside the first epoch
+        std::vector<typename csr_matrix<x_t, v_t, r_t>::plan_want> wants;
+        const int dev = mggcn_get_device();
+        for (std::size_t i = 1; i < sizes.size(); i++) {
+            wants.push_back({A_T, std::min(sizes[i - 1], sizes[i]), dev});             // forward multiplies by A_T (:954)
+            if (i != 1) wants.push_back({A, std::min(sizes[i - 1], sizes[i]), dev});   // the first layer's backward SpMM is skipped
+        }
+        csr_matrix<x_t, v_t, r_t>::prebuild_plans(wants);
     }
 
     // test constructor with given weights (reference :957-963)

@@ -22,6 +22,7 @@
 #include <tuple>
 #include <type_traits>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "mg_gcn.hpp"
@@ -225,6 +226,41 @@ public:
             slot.first = max_d;
         }
         return slot.second;
+    }
+
+    // Builds the plans (matrix, width, device) of a model CONCURRENTLY -- up to four host threads at a time, each plan
+    // builder threading its own passes -- and files them in the matrices' caches: a model multiplies by two matrices at
+    // two widths (four plans of 0.4-1.0 s of host work each at the Reddit shape), which built one after the other on
+    // first use were 2.9 s inside the first epoch -- more than twenty epochs of training; the single-process P-GPU form
+    // has 8 x (1 + 4) per matrix and width.  Entries whose plan exists already (or repeat an earlier entry) are skipped.
+    struct plan_want { csr_matrix A; std::size_t d; int dev; };
+    static void prebuild_plans(const std::vector<plan_want> &wants, std::size_t max_parallel = 4) {
+        struct job { std::shared_ptr<storage> st; int dev; unsigned form, max_d, d; mggcn_spmm_plan *out = nullptr; };
+        std::vector<job> jobs;
+        for (const auto &w : wants) {
+            const unsigned form = (w.d >= 1 && w.d <= 64) ? (unsigned)((w.d + 15) / 16) : 0u;
+            const unsigned max_d = (unsigned)std::max<std::size_t>(w.d, 128);
+            const auto it = w.A.st_->plans.find({w.dev, form});
+            if (it != w.A.st_->plans.end() && it->second.second && it->second.first >= max_d) continue;
+            bool dup = false;
+            for (auto &j : jobs)
+                if (j.st == w.A.st_ && j.form == form && j.dev == w.dev) { dup = true; if (max_d > j.max_d) { j.max_d = max_d; j.d = (unsigned)w.d; } }
+            if (!dup) jobs.push_back({w.A.st_, w.dev, form, max_d, (unsigned)w.d});
+        }
+        const int dev0 = mggcn_get_device();
+        for (std::size_t lo = 0; lo < jobs.size(); lo += max_parallel) {
+            std::vector<std::thread> th;
+            for (std::size_t k = lo; k < std::min(jobs.size(), lo + max_parallel); k++)
+                th.emplace_back([&jobs, k] {
+                    job &j = jobs[k];
+                    mggcn_set_device(j.dev);
+                    j.out = mggcn_spmm_plan_create_for(j.st->N, j.st->M, j.st->indptr.data(), j.st->indices.data(), j.st->data.data(),
+                                                       j.max_d, j.d);
+                });
+            for (auto &t : th) t.join();
+        }
+        for (auto &j : jobs) j.st->plans[{j.dev, j.form}] = {j.max_d, spmm_buffer(j.out, &mggcn_spmm_plan_destroy)};
+        mggcn_set_device(dev0);
     }
 
     // reference src/matrix.hpp:392-453

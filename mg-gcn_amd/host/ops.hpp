@@ -154,6 +154,18 @@ dist_spmm_buffers get_matmul_buffer(const dist_context ctx, const dist_row_csr_m
     const auto P = ctx.size();
     out.block.resize(P);
     out.piece.resize(P);
+    {   // every rank's plans of this width, built side by side (csr_matrix::prebuild_plans), then picked up below
+        std::vector<typename csr_matrix<x_t, v_t, r_t>::plan_want> wants;
+        for (std::size_t j = 0; j < P; j++) {
+            const int dev = (int)ctx[j].device();
+            for (std::size_t i = 0; i < P; i++)
+                if (mode == dist_mode::rounds || i == j) wants.push_back({A[{j, i}], B.m(), dev});
+            if (mode == dist_mode::allgather && P > 1)
+                for (std::size_t c = 0; c < A.chunks(); c++) wants.push_back({A.remote_chunk(j, c), B.m(), dev});
+            if (mode == dist_mode::halo && P > 1) wants.push_back({A.halo_remote(j), B.m(), dev});
+        }
+        csr_matrix<x_t, v_t, r_t>::prebuild_plans(wants);
+    }
     for (std::size_t j = 0; j < P; j++) {
         ctx[j].set();
         out.block[j].resize(P);
