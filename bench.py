@@ -385,18 +385,23 @@ def comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers,
         ver = None
     rep = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": devices, "rccl_version": ver,
            "mode": args.mode, "overlap": not args.no_overlap, "rehearsal_gloo_on_one_gpu": bool(rehearsal)}
-    dctx.profile_exchange = True
     ex, wt = [], []
-    for it in range(3):
-        epoch()
-        if it == 0:
-            continue                                              # first pass creates the events
-        for t in spmm_timers:                                     # "<layer>_<0|1>_matmul-spmm"
-            base = t[: -len("matmul-spmm")]
-            names = [k for k in dctx.ctx.timers if k.startswith(base)]
-            ex.append(sum(dctx.measure(k) for k in names if k.endswith("matmul-exchange")))
-            wt.append(sum(dctx.measure(k) for k in names if k.endswith("matmul-bcast-wait")))
-    dctx.profile_exchange = False
+    try:                                  # the headline is already measured: a failure here must not cost the line
+        dctx.profile_exchange = True
+        for it in range(3):
+            epoch()
+            if it == 0:
+                continue                                          # first pass creates the events
+            for t in spmm_timers:                                 # "<layer>_<0|1>_matmul-spmm"
+                base = t[: -len("matmul-spmm")]
+                names = [k for k in dctx.ctx.timers if k.startswith(base)]
+                ex.append(sum(dctx.measure(k) for k in names if k.endswith("matmul-exchange")))
+                wt.append(sum(dctx.measure(k) for k in names if k.endswith("matmul-bcast-wait")))
+    except Exception as e:                # noqa: BLE001 -- reported in the line
+        rep["exchange_error"] = repr(e)[:200]
+        ex = []
+    finally:
+        dctx.profile_exchange = False
     if ex:
         e, w = float(np.mean(ex)), float(np.mean(wt))
         both = torch.tensor([e, w], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
