@@ -369,6 +369,13 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
+def dist_min_is_negative(torch, dist, ex, rehearsal):
+    """did ANY rank fail its exchange-timing pass?  (one MIN all-reduce, executed by every rank)"""
+    flag = torch.tensor([1.0 if ex else -1.0], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return float(flag[0]) < 0
+
+
 def comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers, args):
     """N > 1: what the run exchanged over -- backend, communicator size, every rank's device, the RCCL version -- and
     one SEPARATE pass of 3 epochs (after the timed ones) with the exchange events on: per d-wide SpMM the comm-stream
@@ -402,13 +409,14 @@ def comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers,
         ex = []
     finally:
         dctx.profile_exchange = False
-    if ex:
-        e, w = float(np.mean(ex)), float(np.mean(wt))
-        both = torch.tensor([e, w], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(both, op=dist.ReduceOp.MAX)
-        e, w = float(both[0]), float(both[1])
-        rep.update({"exchange_ms": round(e, 4), "exposed_ms": round(w, 4),
-                    "overlap_frac": round(1.0 - w / e, 4) if e > 0 else None,
+    # every rank takes part in this reduction whatever happened above (a rank whose pass failed is seen by the MIN reduction below)
+    e, w = (float(np.mean(ex)), float(np.mean(wt))) if ex else (0.0, 0.0)
+    both = torch.tensor([e, w], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    dist.all_reduce(both, op=dist.ReduceOp.MAX)
+    failed = dist_min_is_negative(torch, dist, ex, rehearsal)
+    e, w = float(both[0]), float(both[1])
+    if not failed and e > 0:
+        rep.update({"exchange_ms": round(e, 4), "exposed_ms": round(w, 4), "overlap_frac": round(1.0 - w / e, 4),
                     "exchange_note": "per d-wide SpMM, max over ranks, separate pass after the timed epochs"})
     return rep
 
