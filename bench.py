@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--hidden", type=int, nargs="*", default=[128, 128, 128])
     ap.add_argument("--mode", default="allgather", choices=["allgather", "halo", "rounds"])
     ap.add_argument("--no-overlap", action="store_true", help="the reference's -S flag")
+    ap.add_argument("--chunks", type=int, default=0, help="pieces of the all-gather exchange (0 = default: 2 at N = 2, 4 above)")
     ap.add_argument("--unfused", action="store_true", help="reference launch sequence, no fused kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -115,6 +116,8 @@ def main():
                     help="HEADLINE workload = the symmetric stand-in (pattern A = A^T like the real Reddit); manual mode")
     args = ap.parse_args()
 
+    if args.chunks > 0:
+        os.environ["MGGCN_DIST_CHUNKS"] = str(args.chunks)
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
     # stdout when its first communicator comes up; gloo prints its rank table): everything this process writes to
     # file descriptor 1 from here on goes to stderr, and the JSON line goes to the real stdout at the end.
@@ -391,7 +394,8 @@ def comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers,
     except Exception:
         ver = None
     rep = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": devices, "rccl_version": ver,
-           "mode": args.mode, "overlap": not args.no_overlap, "rehearsal_gloo_on_one_gpu": bool(rehearsal)}
+           "mode": args.mode, "overlap": not args.no_overlap, "rehearsal_gloo_on_one_gpu": bool(rehearsal),
+           "chunks": int(os.environ.get("MGGCN_DIST_CHUNKS", "0")) or None}
     ex, wt = [], []
     try:                                  # the headline is already measured: a failure here must not cost the line
         dctx.profile_exchange = True

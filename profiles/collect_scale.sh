@@ -28,15 +28,23 @@ for N in 2 4 8; do
     done
   done
 done
+# the all-gather exchange in 1 / 2 / 8 pieces at the largest N (default is 4: every piece is one more collective)
+for K in 1 2 8; do
+  PORT=$((PORT + 1))
+  echo "N=8 mode=allgather chunks=$K" >&2
+  timeout -k 10 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+    --master-port "$PORT" "$ROOT/bench.py" --gpus 8 --steps "$STEPS" --warmup "$WARMUP" --mode allgather --chunks "$K" >> "$OUT" \
+    || echo "{\"error\": \"N=8 allgather chunks=$K\"}" >> "$OUT"
+done
 python3 - "$OUT" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
 base = next((r["value"] for r in rows if r.get("n_gpus") == 1), None)
-print("| N | mode | overlap | epoch ms | speed-up | exchange ms / SpMM | exposed ms | overlap frac |\n|---|---|---|---|---|---|---|---|")
+print("| N | mode (pieces) | overlap | epoch ms | speed-up | exchange ms / SpMM | exposed ms | overlap frac |\n|---|---|---|---|---|---|---|---|")
 for r in rows:
     if "error" in r:
         print("|", r["error"], "| failed |||||||"); continue
     c = r.get("comm") or {}
-    print(f"| {r['n_gpus']} | {c.get('mode', '-')} | {c.get('overlap', '-')} | {r['value']:.3f} | "
+    print(f"| {r['n_gpus']} | {c.get('mode', '-')} ({c.get('chunks') or 'default'}) | {c.get('overlap', '-')} | {r['value']:.3f} | "
           f"{(base / r['value']) if base else float('nan'):.2f} | {c.get('exchange_ms', '-')} | {c.get('exposed_ms', '-')} | {c.get('overlap_frac', '-')} |")
 PY
