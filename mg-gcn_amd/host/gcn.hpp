@@ -338,8 +338,14 @@ class gcn_layer {
     // fused backward (set by the model): mask_input_grad -- my G_out GEMM applies leaky_relu'(H) of the layer
     // below; grad_premasked -- the G I receive already carries my own activation's mask
     bool mask_input_grad = false, grad_premasked = false;
+    // optional, first layer only (gcn::set_hoist_first_aggregation): A_fwd . X computed once and kept
+    bool hoist_input = false;
+    dn_matrix<r_t> AX;
+    const r_t *AX_src = nullptr;
 
 public:
+    void set_hoist_input(bool on) { hoist_input = on && gemm_first() && !residual_layer; if (!on) { AX = dn_matrix<r_t>(); AX_src = nullptr; } }
+    bool hoists_input() const { return hoist_input; }
     bool gemm_first() const { return HW.m() == AHW.m(); }           // out <= in (reference :439)
     bool has_activation() const { return activation; }
     bool propagates() const { return lin.has_backward_out(); }
@@ -367,7 +373,18 @@ public:
     auto operator()(context ctx, dn_matrix<r_t> H) {
         this->H = H;
         bool act_done = false;
-        if (HW.m() == AHW.m()) {                 // out <= in: GEMM first (reference :439-442)
+        if (hoist_input && HW.m() == AHW.m()) {
+            // layer 0's aggregation is loop-invariant: A_fwd (X W + 1 b^T) = (A_fwd X) W + 1 b^T (A_fwd is row-stochastic,
+            // X never changes between epochs): A_fwd X once, one SpMM fewer per epoch.  NOT the reference's epoch
+            // (:437-446): an option, off by default.  The backward pass stays the reference's (G_W = X^T T, :954).
+            if (!AX.buffer() || AX_src != H.buffer() || AX.n() != AHW.n() || AX.m() != H.m()) {
+                AX = dn_matrix<r_t>(AHW.n(), H.m());
+                A(ctx, H, AX);
+                AX_src = H.buffer();
+            }
+            lin(ctx, AX, AHW);
+            lin.setX(H);
+        } else if (HW.m() == AHW.m()) {          // out <= in: GEMM first (reference :439-442)
             lin(ctx, H, HW);
             if (fused && activation) { A(ctx, HW, AHW, true, MGGCN_SPMM_LEAKY_RELU); act_done = true; }
             else A(ctx, HW, AHW);
@@ -690,6 +707,11 @@ public:
         }
         csr_matrix<x_t, v_t, r_t>::prebuild_plans(wants);
     }
+
+    // Optional mode (never the reference's epoch): pre-compute the first layer's aggregation A_fwd . X once -- valid while
+    // the SAME feature matrix is passed every epoch (full-graph training does); 6 instead of 7 SpMMs per epoch on the
+    // Reddit model.  `mg_gcn` turns it on with MGGCN_HOIST_FIRST_AGGREGATION=1.
+    void set_hoist_first_aggregation(bool on) { layers_.front().set_hoist_input(on); }
 
     // test constructor with given weights (reference :957-963)
     gcn(csr_matrix<x_t, v_t, r_t> A, std::vector<std::size_t> sizes, std::vector<std::pair<std::vector<r_t>, std::vector<r_t>>> weights)

@@ -11,7 +11,9 @@
 // `-R 1` routes through the distributed classes at any P (at -P 1 too: one rank, same schedule).
 // Environment: MGGCN_DIST_MODE=allgather|halo|rounds picks the exchange schedule (ops.hpp; rounds = the
 // reference's broadcast pipeline); MGGCN_FUSED=0 replays the reference's launch sequence;
-// MGGCN_OVERSUBSCRIBE=1 lets -P exceed the visible GPUs (ranks wrap over them, peer-copy transport).
+// MGGCN_OVERSUBSCRIBE=1 lets -P exceed the visible GPUs (ranks wrap over them, peer-copy transport);
+// MGGCN_HOIST_FIRST_AGGREGATION=1 (single GPU) pre-computes the first layer's A.X once (6 SpMMs per epoch: not the
+// reference's epoch, same results at 1e-4); MGGCN_TIMING=1 prints the start-up stages.
 #include <unistd.h>
 
 #include <chrono>
@@ -148,6 +150,7 @@ int main_(int argc, char **argv) {
         if (P <= 1 && !row_partition) {
             auto ctx = context(0);
             gcn<x_t, v_t, r_t> G(A, sizes, false, fused);
+            if (env_is("MGGCN_HOIST_FIRST_AGGREGATION", "1")) G.set_hoist_first_aggregation(true);   // optional 6-SpMM epoch
             ctx.sync();
             stage("model (normalize, transpose, layers)");
             ctx.record("training-start", 0);

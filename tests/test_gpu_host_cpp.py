@@ -114,3 +114,28 @@ def test_cli_row_partition_matches_dist_oracle(pkg, oracle, tmp_path, P, flags, 
     # the file name carries the UNPADDED class count: it is built (src/main.cpp:100-111) before the padding (:135)
     text = (tmp_path / "csvs" / f"permuted_synth_{F}_16_16_{C}_{P}.csv").read_text()
     assert re.search(rf"^0_{P - 1}_0_0_matmul-spmm:", text, re.M)          # per-rank timers "<epoch>_<rank>_<name>"
+
+
+def test_cli_hoisted_first_aggregation_matches_the_plain_run(pkg, oracle, tmp_path):
+    """MGGCN_HOIST_FIRST_AGGREGATION=1 (optional 6-SpMM epoch of the C++ host layer, same option as
+    gcn(hoist_first_aggregation=True) in Python): epoch-0 loss equal to the oracle's and to the plain run's at 1e-4,
+    and it trains."""
+    n, F, C = 1024, 24, 6
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, n * 20, 900, seed=27)
+    rng = np.random.default_rng(28)
+    X = rng.standard_normal((n, F), dtype=np.float32)
+    Y = rng.integers(0, C, size=(n, 1)).astype(np.int32)
+    Y[0, 0] = C - 1
+    d = tmp_path / "permuted" / "synth"
+    pkg.datasets.write_dataset(str(d), ip, ix, dv, X, Y)
+    O = oracle.Gcn(oracle.Csr(ip, ix, dv, n), [F, 16, 16, C])
+    want = O.train_forward(X, Y)
+    got = {}
+    for hoist in ("0", "1"):
+        r = _run([os.path.join(BIN, "mg_gcn"), "-E", "3", "train", str(d), "2", "16", "16"], cwd=str(tmp_path),
+                 env={"MGGCN_HOIST_FIRST_AGGREGATION": hoist})
+        assert r.returncode == 0, r.stderr
+        got[hoist] = [tuple(float(x) for x in ln.split()) for ln in r.stderr.strip().splitlines()[3:6]]
+        assert abs(got[hoist][0][1] - want[0]) <= 1e-4 * want[0]
+        assert got[hoist][2][1] < got[hoist][0][1]
+    assert abs(got["1"][0][1] - got["0"][0][1]) <= 1e-4 * got["0"][0][1]
