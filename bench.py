@@ -118,6 +118,14 @@ def main():
 
     if args.chunks > 0:
         os.environ["MGGCN_DIST_CHUNKS"] = str(args.chunks)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "MGGCN_HOST_THREADS" not in os.environ:
+        # N ranks share this host: every rank builds up to four SpMM plans side by side and each plan builder starts
+        # MGGCN_HOST_THREADS threads (default: all the cores it can see) -- keep the node's total in the hundreds
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 8
+        os.environ["MGGCN_HOST_THREADS"] = str(max(2, min(16, avail // (4 * int(os.environ["WORLD_SIZE"])) or 2)))
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
     # stdout when its first communicator comes up; gloo prints its rank table): everything this process writes to
     # file descriptor 1 from here on goes to stderr, and the JSON line goes to the real stdout at the end.
