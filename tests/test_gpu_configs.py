@@ -340,8 +340,9 @@ def test_c5_papers100m_rank_share(pkg, ctx):
     assert bool((C.t == C.t[:, :1]).all().item())          # every column of M 1 is the same vector
 
 
-def _time_spmm(pkg, ctx, M, d, calls=5, reps=3):
-    B = pkg.dn_matrix.from_numpy(np.random.default_rng(d).standard_normal((M.m(), d), dtype=np.float32))
+def _time_spmm(pkg, ctx, M, d, calls=5, reps=3, check_rows=0):
+    Bh = np.random.default_rng(d).standard_normal((M.m(), d), dtype=np.float32)
+    B = pkg.dn_matrix.from_numpy(Bh)
     C = pkg.dn_matrix(M.n(), d)
     buf = pkg.get_matmul_buffer(ctx, M, B, C, max_d=128)
     for _ in range(2):
@@ -353,6 +354,9 @@ def _time_spmm(pkg, ctx, M, d, calls=5, reps=3):
             pkg.matmul(ctx, M, B, C, buf, 1.0, 0.0)
         ctx.record("t_b", 0); ctx.sync(); ctx.register_timer("t_ab", "t_a", "t_b")
         ts.append(ctx.measure("t_ab") / calls)
+    if check_rows:                                  # ... and the result, on sampled rows in fp64
+        rows = sample_rows(M, check_rows, np.random.default_rng(1))
+        assert_rows_close(C.numpy()[rows].astype(np.float64), rows_fp64(M, Bh, rows), "order-invariance")
     return float(np.median(ts)), buf.describe()
 
 
@@ -367,7 +371,7 @@ def test_c2_spmm_time_does_not_depend_on_the_input_order(pkg, ctx):
     ip, ix, dv, n = data["ip"], data["ix"], data["dv"], data["n"]
     A = pkg.csr_matrix(ip, ix, dv.copy(), n)
     A.normalize(True)
-    t_sorted, desc = _time_spmm(pkg, ctx, A, 128)
+    t_sorted, desc = _time_spmm(pkg, ctx, A, 128, check_rows=256)
     assert "permuted=0" in desc
     rng = np.random.default_rng(0)
     rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(ip.astype(np.int64)))
@@ -382,6 +386,6 @@ def test_c2_spmm_time_does_not_depend_on_the_input_order(pkg, ctx):
     M = sp.csr_matrix((A.data, ix, ip.astype(np.int64)), shape=(n, n))[perm][:, perm]
     M.sort_indices()
     D = pkg.csr_matrix(M.indptr.astype(np.uint32), M.indices.astype(np.uint32), M.data.astype(np.float32), n)
-    t_degree, desc = _time_spmm(pkg, ctx, D, 128)
+    t_degree, desc = _time_spmm(pkg, ctx, D, 128, check_rows=256)     # the column-permuted plan at full size, fp64 rows
     assert "permuted=1" in desc                                        # locality 0.11 >= 0.08
     assert t_degree <= 1.12 * t_shuffled, (t_degree, t_shuffled)
