@@ -282,9 +282,9 @@ __global__ __launch_bounds__(NT, 4) void gemm_mfma_kernel(   // 4 waves per SIMD
         }
     };
     using q0 = std::integral_constant<int, 0>;
-    using q1 = std::integral_constant<int, BK / 8>;
+    using q1 [[maybe_unused]] = std::integral_constant<int, BK / 8>;     // quarters: MGGCN_GEMM_QUARTERS builds only
     using q2 = std::integral_constant<int, BK / 4>;
-    using q3 = std::integral_constant<int, 3 * BK / 8>;
+    using q3 [[maybe_unused]] = std::integral_constant<int, 3 * BK / 8>;
     using q4 = std::integral_constant<int, BK / 2>;
     // one K-step: tile (k0) is in LDS buffer CUR; set NXT holds tile k0 + BK (in flight or landed); set CUR is free.
     // The memory work of the step is dealt out between the four quarters of the MFMA sequence, so a wave never leaves
