@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
+BENCH="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras ${BENCH_ARGS:-}"   # BENCH_ARGS=--symmetric: the symmetric stand-in
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- $BENCH > $O/bench_under_rocprof.json 2> $O/stats.err
 echo "stats done"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- $BENCH > /dev/null 2> $O/fetch.err

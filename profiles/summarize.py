@@ -48,6 +48,7 @@ def main():
                     help="kernel launches that make up ONE mggcn_spmm_csr_f32 call (sweep form: rounds)")
     ap.add_argument("--narrow-kernel", default=None, help="second SpMM kernel (the logits-width form)")
     ap.add_argument("--narrow-launches-per-unit", type=float, default=1)
+    ap.add_argument("--no-json", action="store_true", help="summary only: leave spmm_hbm_traffic.json (the headline workload's) alone")
     a = ap.parse_args()
 
     lines = []
@@ -89,7 +90,8 @@ def main():
                 rec["kernel_launches_per_spmm_call_narrow"] = a.narrow_launches_per_unit
                 lines.append(f"narrow kernel `{a.narrow_kernel}`: traffic beyond L2 = {tn / 1e9:.2f} GB per SpMM call "
                              f"({a.narrow_launches_per_unit} kernel launch(es) per call)")
-            json.dump(rec, open(os.path.join(HERE, "spmm_hbm_traffic.json"), "w"), indent=1)
+            if not a.no_json:
+                json.dump(rec, open(os.path.join(HERE, "spmm_hbm_traffic.json"), "w"), indent=1)
     out = os.path.join(HERE, f"{a.tag}_summary.md")
     open(out, "w").write("\n".join(lines) + "\n")
     print(open(out).read())
