@@ -3,6 +3,8 @@ tests proper).  Floating-point bar: 1e-4 relative (BASELINE.json north_star), me
 as max|got - want| / max|want| per output and, for the SpMM, additionally row by row
 against the fp64-accumulated oracle so that a wrong row cannot hide behind a large one.
 Integer outputs (argmax, is_equal) are bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -603,3 +605,17 @@ def test_gemm_tn_colsum_equals_the_two_gemms(pkg, oracle, ctx, n, din, dout):
     want = oracle.gemm(np.ones((1, n), np.float32), G, f64acc=True)
     assert relerr(Gb.numpy(), want) <= TOL and relerr(Gb2.numpy(), want) <= TOL
     assert relerr(GW.numpy(), oracle.gemm(X, G, A_T=True, f64acc=True)) <= TOL
+
+
+def test_spmm_random_shapes_forms_and_knobs(pkg):
+    """A bounded run of profiles/experiments/spmm_fuzz_r03.py: random shapes (1 x 1 up to 9000 x 20000), degree laws (empty rows,
+    giant rows, duplicates, one-column matrices), widths 1..608, alpha / beta / fused activation, NaN-filled C at beta = 0, and a
+    random plan form per case (heuristics, forced sweep with random panel / slice / permutation / rows-per-task knobs, row-split,
+    no plan) against scipy in fp64 at 1e-4 of the row's sum|a||b| budget.  (5000 cases of it ran clean in round 3:
+    profiles/experiments/spmm_fuzz_r03.log, worst 4.1e-7.)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("spmm_fuzz", os.path.join(root, "profiles", "experiments", "spmm_fuzz_r03.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.main(cases=250, seed=2026) == 0
