@@ -619,3 +619,16 @@ def test_spmm_random_shapes_forms_and_knobs(pkg):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.main(cases=250, seed=2026) == 0
+
+
+def test_gemm_random_shapes_transposes_and_epilogues(pkg):
+    """A bounded run of profiles/experiments/gemm_fuzz_r03.py: mggcn_gemm_f32 (all transposes, alpha / beta, NaN-filled C at
+    beta = 0), the bias, leaky-ReLU-backward and X^T G + column-sum epilogues over random (M, N, K) from 1 to 5000 x 5000 x 30000
+    (odd sizes, split-K lengths, K below one MFMA step) against numpy in fp64 at 1e-4 of the entry's sum|a||b| budget.
+    (1500 cases ran clean in round 3: profiles/experiments/gemm_fuzz_r03.log, worst 3.5e-7.)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gemm_fuzz", os.path.join(root, "profiles", "experiments", "gemm_fuzz_r03.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.run(cases=200, seed=2026) == 0
