@@ -168,7 +168,7 @@ static void compare(std::size_t P, const epoch_result &d, const epoch_result &s,
             }
         }
     }
-    CHECK(d.loss[1] < d.loss[0]);
+    CHECK((d.loss[1] < d.loss[0]) == (s.loss[1] < s.loss[0]));      // training moves the way the single-GPU model moves (a width-1 bottleneck may go up)
     for (std::size_t l = 0; l < s.W1.size(); l++) {
         if (P == 1) {
             CHECK(d.W1[l] == s.W1[l]);
@@ -184,13 +184,18 @@ static void compare(std::size_t P, const epoch_result &d, const epoch_result &s,
 }
 
 int main(int argc, char **argv) {
+    // test_dist P [n graph_seed F C hidden...]: the defaults are the fixed case of the suite; tests/test_gpu_host_cpp.py also
+    // walks a few random shapes (odd widths, one hidden layer, class counts that need padding to a multiple of P)
     const std::size_t P = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1;
-    const v_t n = 1536;                                      // divisible by 1, 2, 3, 4, 6, 8
-    if (n % P != 0) { std::fprintf(stderr, "P must divide %u\n", n); return 2; }
+    const v_t n = argc > 2 ? (v_t)std::strtoull(argv[2], nullptr, 10) : 1536;      // 1536: divisible by 1, 2, 3, 4, 6, 8
+    if (P == 0 || n % P != 0) { std::fprintf(stderr, "P must divide %u\n", n); return 2; }
     mggcn_set_device(0);
-    const auto A = make_graph(n, 42);
-    const std::size_t F = 24, C = 6;
-    std::vector<std::size_t> sizes{F, 32, 16, (C + P - 1) / P * P};      // first layer out > in: SpMM first; src/main.cpp:135
+    const auto A = make_graph(n, argc > 3 ? (std::uint32_t)std::strtoull(argv[3], nullptr, 10) : 42u);
+    const std::size_t F = argc > 4 ? std::strtoull(argv[4], nullptr, 10) : 24, C = argc > 5 ? std::strtoull(argv[5], nullptr, 10) : 6;
+    std::vector<std::size_t> sizes{F};
+    if (argc > 6) for (int i = 6; i < argc; i++) sizes.push_back(std::strtoull(argv[i], nullptr, 10));
+    else { sizes.push_back(32); sizes.push_back(16); }                    // first layer out > in: SpMM first
+    sizes.push_back((C + P - 1) / P * P);                                 // src/main.cpp:135
     lcg g{7};
     std::vector<float> xs(n * F);
     for (auto &x : xs) x = 2.f * g.unit() - 1.f;

@@ -87,6 +87,22 @@ def test_cpp_dist_classes_match_single_gpu(P):
     assert ("transport=rccl" in r.stdout) == (P == 1) and ("transport=p2p" in r.stdout) == (P > 1)
 
 
+# (P, n, graph seed, F, C, hidden...): corners nobody chose -- shards of 8 rows, one hidden layer, none, width-1 layers, class
+# counts that need padding to a multiple of P (src/main.cpp:135), eight ranks, K pieces longer than a shard has rows to give
+DIST_SHAPES = [(2, 16, 1, 3, 2), (3, 393, 2, 1, 7, 5), (4, 64, 3, 33, 5, 1, 40), (8, 1024, 4, 16, 41, 128), (3, 1500, 5, 100, 3, 2, 2, 2),
+               (8, 64, 6, 5, 9, 8), (6, 774, 7, 24, 47, 33, 17), (5, 1000, 8, 608, 4, 16), (2, 3000, 9, 7, 2, 200, 1, 64)]
+
+
+@pytest.mark.parametrize("shape", DIST_SHAPES, ids=lambda s: "P%d-n%d-F%d-C%d-%s" % (s[0], s[1], s[3], s[4], "x".join(map(str, s[5:])) or "none"))
+def test_cpp_dist_classes_on_odd_shapes(shape):
+    """the same binary on shapes off the beaten path: every schedule x overlap x fused against the single-GPU model, two epochs at
+    1e-4 (host/tests/test_dist.cpp takes `P n seed F C hidden...`)"""
+    r = _run([os.path.join(BIN, "test_dist")] + [str(x) for x in shape], env={"MGGCN_OVERSUBSCRIBE": "1"})
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "TEST FAILED" not in r.stdout
+    assert r.stdout.count("TEST PASSED") >= 12, r.stdout
+
+
 @pytest.mark.parametrize("P,flags,mode", [(1, [], "allgather"), (2, [], "allgather"), (2, ["-S", "x"], "halo"),
                                           (4, [], "rounds")])
 def test_cli_row_partition_matches_dist_oracle(pkg, oracle, tmp_path, P, flags, mode):
