@@ -95,16 +95,20 @@ def _oracle_epochs(O, X, Y, epochs):
     return want, resync
 
 
-def _assert_epochs_match(rank, out, want, n):
+def _assert_epochs_match(rank, out, want, n, model_floor=0.0):
+    """model_floor: a gradient tensor is held to 1e-4 of max(its own largest entry, model_floor x the model's largest
+    gradient entry) -- 0 for the regular shapes; the odd-shape cases (width-1 bottlenecks) have layers whose whole gradient
+    is rounding noise next to the others"""
     for e, ((loss, acc, grads, gb), (ol, oa, oG, oGb)) in enumerate(zip(out, want)):
         assert abs(loss - ol) <= 1e-4 * abs(ol), (rank, e, loss, ol)       # EVERY epoch at the north-star bar
         assert abs(acc - oa) <= 3.0 / n, (rank, e, acc, oa)
         if grads is None:
             continue
+        gmax = max(np.abs(og).max() for og in list(oG) + list(oGb))
         for g, og in zip(grads, oG):                                        # all-reduced gradients, every rank
-            assert np.abs(g - og).max() <= 1e-4 * np.abs(og).max(), (rank, e)
+            assert np.abs(g - og).max() <= 1e-4 * max(np.abs(og).max(), model_floor * gmax), (rank, e)
         for g, og in zip(gb, oGb):
-            assert np.abs(g - og).max() <= 1e-4 * np.abs(og).max(), (rank, e)
+            assert np.abs(g - og).max() <= 1e-4 * max(np.abs(og).max(), model_floor * gmax), (rank, e)
 
 
 @pytest.mark.parametrize("P,mode,chunks,overlap", [
@@ -114,7 +118,20 @@ def _assert_epochs_match(rank, out, want, n):
     # src/main.cpp:66) -- same results, every schedule
     (2, "allgather", None, False), (2, "rounds", None, False), (2, "halo", None, False)])
 def test_dist_gcn_matches_oracle(oracle, P, mode, chunks, overlap):
-    n, F, C, hidden, epochs = 1536, 20, 5, [16, 16], 3
+    _dist_case(oracle, P, mode, chunks, overlap, 1536, 20, 5, [16, 16], 3)
+
+
+# corners nobody chose: shards of 8 rows, no hidden layer, width-1 layers, class counts padded to a multiple of P, more pieces
+# than a shard has rows, five ranks (the box allows six GPU processes)
+@pytest.mark.parametrize("P,mode,chunks,overlap,n,F,C,hidden", [
+    (2, "allgather", None, True, 16, 3, 2, []), (3, "halo", None, True, 393, 1, 7, [5]), (4, "rounds", None, True, 64, 33, 5, [1, 40]),
+    (2, "allgather", 5, False, 3000, 7, 2, [200, 1, 64]), (5, "allgather", None, True, 1000, 100, 4, [16]),
+    (4, "halo", None, False, 32, 5, 9, [8]), (2, "allgather", 64, True, 16, 2, 3, [4])])
+def test_dist_gcn_on_odd_shapes(oracle, P, mode, chunks, overlap, n, F, C, hidden):
+    _dist_case(oracle, P, mode, chunks, overlap, n, F, C, hidden, 3, must_train=False, model_floor=1e-2)
+
+
+def _dist_case(oracle, P, mode, chunks, overlap, n, F, C, hidden, epochs, must_train=True, model_floor=0.0):
     _, (ip, ix, dv), X, Y = _data(n, F, C)
     O = oracle.DistGcn(oracle.Csr(ip, ix, dv, n), [F] + hidden + [C], P)
     want, resync = _oracle_epochs(O, X, Y, epochs)
@@ -130,8 +147,8 @@ def test_dist_gcn_matches_oracle(oracle, P, mode, chunks, overlap):
         pr.join(timeout=60)
         assert pr.exitcode == 0
     for rank, out, W in res:
-        _assert_epochs_match(rank, out, want, n)
-        assert out[-1][0] < out[0][0]                                       # trains
+        _assert_epochs_match(rank, out, want, n, model_floor)
+        assert out[-1][0] < out[0][0] or not must_train                     # trains
     # replicated weights stay bitwise identical across ranks (same all-reduced gradient, same Adam)
     for li in range(len(res[0][2])):
         for r in range(1, P):
