@@ -223,6 +223,21 @@ int main(int argc, char **argv) {
     // halo volume matrix of the partition (the figure test/data/prep.py:237-244 prints)
     if (P > 1) {
         dist_context ctx(P);
+        CHECK((std::size_t)mggcn_comm_size(ctx.comm()) == P);
+        {   // the exported displacement tables (include/mggcn_comm.h) on a ragged count matrix: prefix sums per sender / receiver
+            std::vector<std::size_t> counts(P * P), sdis(P * P), rdis(P * P);
+            for (std::size_t q = 0; q < P * P; q++) counts[q] = (q * 7 + 3) % 11;
+            mggcn_comm_alltoallv_displacements((int)P, counts.data(), sdis.data(), rdis.data());
+            for (std::size_t j = 0; j < P; j++) {
+                std::size_t s = 0, r = 0;
+                for (std::size_t k = 0; k < P; k++) {
+                    CHECK(sdis[j * P + k] == s);
+                    CHECK(rdis[j * P + k] == r);
+                    s += counts[j * P + k];                 // what j sends to k
+                    r += counts[k * P + j];                 // what j receives from k
+                }
+            }
+        }
         std::vector<v_t> p(P + 1);
         for (std::size_t i = 1; i < p.size(); i++) p[i] = (v_t)(i * n / P);
         dist_row_csr_matrix<x_t, v_t, r_t> Ad(ctx, A, p, p);
