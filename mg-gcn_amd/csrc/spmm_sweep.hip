@@ -27,7 +27,8 @@
 // never depend on it.
 //
 // Kernels in this file (dispatch: sweep_launch):
-//   spmm_sweep_pair_kernel        d % 4 == 0, d >= 96: two 512-byte rows per buffer_load_dwordx4
+//   spmm_sweep_pair_kernel<FAST>  d % 4 == 0, d >= 96: two 512-byte rows per buffer_load_dwordx4; <true> when the row pitch
+//                                 is a power of two (d = 128 contiguous): four instructions fewer per pair
 //   spmm_sweep_quad_lds_kernel<L> d <= 64 (plan built with a width hint): 64/L rows per load,
 //                                 entries staged through LDS
 //   spmm_sweep_kernel<1|2>        every other width / alignment: one row per load
@@ -356,6 +357,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void spmm_sweep_kernel(
 // sums of the SAME output row (the run's row is still wave-uniform -> index-mode fold); the
 // halves are added once per task at write-out.
 // ---------------------------------------------------------------------------------------
+// FAST (row pitch a power of two >= 512 bytes, i.e. d = 128 contiguous): three scalar and two vector instructions fewer per pair.
+//   * offset = packed word x pitch WITHOUT masking the flag / row bits off first: they sit at bit 27 and up, the pitch is a
+//     multiple of 32, so they leave the 32-bit product;
+//   * the upper half's extra offset is a multiple of the pitch and the lane's own offset is below it: OR instead of ADD, fused
+//     with the AND of the half mask (v_and_or_b32);
+//   * the half's value through v_bfi_b32 (one move + one select instead of three instructions).
+// The per-wave instruction chain is on the critical path of this kernel (profiles/experiments/split_pairs_r03.log: six
+// more instructions per pair cost 16 % per batch).
+template <bool FAST>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr(64))) void spmm_sweep_pair_kernel(
     const SweepTask *__restrict__ tasks, uint32_t task0, uint32_t n_launch,
     const uint2 *__restrict__ entries, const uint32_t *__restrict__ task_rows,
@@ -402,8 +412,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
                 for (int u = 0; u < 4; u++) {
                     const uint32_t off_a = (cur.pk(2 * u) & kColMask) * row_bytes;
                     const uint32_t off_b = (cur.pk(2 * u + 1) & kColMask) * row_bytes;     // >= off_a
-                    const uint32_t voff = lane_off + ((off_b - off_a) & hmask);
-                    b[u] = mggcn_buffer_load_v4f32(rsrc, (int)voff, (int)off_a, MGGCN_GATHER_AUX);
+                    if constexpr (FAST) {
+                        const uint32_t fa = cur.pk(2 * u) * row_bytes, fb = cur.pk(2 * u + 1) * row_bytes;
+                        const uint32_t voff = lane_off | ((fb - fa) & hmask);
+                        b[u] = mggcn_buffer_load_v4f32(rsrc, (int)voff, (int)fa, MGGCN_GATHER_AUX);
+                    } else {
+                        const uint32_t voff = lane_off + ((off_b - off_a) & hmask);
+                        b[u] = mggcn_buffer_load_v4f32(rsrc, (int)voff, (int)off_a, MGGCN_GATHER_AUX);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -415,7 +431,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
                     }
                     const uint32_t va = __builtin_bit_cast(uint32_t, cur.val(2 * u));
                     const uint32_t vb = __builtin_bit_cast(uint32_t, cur.val(2 * u + 1));
-                    const float v = __builtin_bit_cast(float, (va & ~hmask) | (vb & hmask));
+                    float v;
+                    if constexpr (FAST) {
+                        uint32_t sel;
+                        asm("v_mov_b32 %0, %1\n\tv_bfi_b32 %0, %2, %3, %0" : "=&v"(sel) : "s"(va), "v"(hmask), "s"(vb));
+                        v = __builtin_bit_cast(float, sel);
+                    } else {
+                        v = __builtin_bit_cast(float, (va & ~hmask) | (vb & hmask));
+                    }
+                    // (starting the new run from the product v * b instead of zeroing acc, and dropping the clamp of the
+                    //  prefetch index, were measured on top of FAST: +2 % and +-0: profiles/experiments/fast_pairs_r03.log)
                     acc[0] = fmaf(v, b[u][0], acc[0]);
                     acc[1] = fmaf(v, b[u][1], acc[1]);
                     acc[2] = fmaf(v, b[u][2], acc[2]);
@@ -593,6 +618,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
         uint4 pre = stream[n_chunks > 1 ? CH / 2 : 0];
         const uint32_t prio_slot = blockIdx.x / kNumCU;
         const uint32_t prio_shift = (flags >> kPrioShiftPos) & 15u;          // in chunks of CH (~128) entries here
+        f32x4_t b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) b[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (uint32_t c = 0; c < n_chunks; c++) {
             if ((flags & kFlagPrioRotate) && (c & ((1u << prio_shift) - 1u)) == 0) rotate_priority(prio_slot, c >> prio_shift);
             ring[wib][(c + 1) & 1][lane] = pre;           // chunk c+1 (slot last read during chunk c-1)
@@ -602,11 +630,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
             const uint32_t n_steps = min((uint32_t)(CH / STEP), (n_ent - c * CH) / STEP);
             for (uint32_t s = 0; s < n_steps; s++) {
                 uint2 ent[4];
-                f32x4_t b[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) ent[u] = slot[s * STEP + u * G];
-#pragma unroll
-                for (int u = 0; u < 4; u++) b[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                // (b is zeroed ONCE, in front of the chunk loop: lanes past the row never load and keep their zeros --
+                //  zeroing it here was sixteen v_mov per step, four per gather)
                 if (active) {                                    // lanes past the row issue no load (3 % faster)
 #pragma unroll
                     for (int u = 0; u < 4; u++)
@@ -754,7 +781,7 @@ struct SweepPlan {
     uint64_t n_entries = 0;        // padded entry stream length
     uint32_t prio_bits_wide = 0, prio_bits_narrow = 0;   // kFlagPrioRotate | shift << kPrioShiftPos, or 0
     uint32_t tasks_per_wave = 1;
-    bool allow_quad = true, allow_vec4 = true;
+    bool allow_quad = true, allow_vec4 = true, fast_pairs = true;
 };
 
 SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
@@ -1047,6 +1074,7 @@ SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *in
         p->tasks_per_wave = std::max(1u, env_u32("MGGCN_SPMM_TASKS_PER_WAVE", 1u));
         p->allow_quad = env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) != 0;
         p->allow_vec4 = env_u32("MGGCN_SPMM_SWEEP_VEC4", 1u) != 0;
+        p->fast_pairs = env_u32("MGGCN_SPMM_FAST_PAIRS", 1u) != 0;
     }
     const size_t tb = tasks.size() * sizeof(SweepTask), eb = entries.size() * sizeof(uint2);
     const size_t rb = task_rows.size() * sizeof(uint32_t), sb = split_rows.size() * sizeof(SweepSplitRow);
@@ -1173,8 +1201,12 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
             else MGGCN_LAUNCH_NARROW(16);
         }
 #undef MGGCN_LAUNCH_NARROW
+        else if (vec4 && row_bytes >= 512u && (row_bytes & (row_bytes - 1u)) == 0 && p->fast_pairs)   // power-of-two pitch
+            hipLaunchKernelGGL((spmm_sweep_pair_kernel<true>), grid, block, 0, st, p->d_tasks, t0, n_launch,
+                               p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
+                               alpha, beta, wide_flags, slope, p->d_stamps, tpw > 1 ? p->round_tasks : n_launch);
         else if (vec4)
-            hipLaunchKernelGGL(spmm_sweep_pair_kernel, grid, block, 0, st, p->d_tasks, t0, n_launch,
+            hipLaunchKernelGGL((spmm_sweep_pair_kernel<false>), grid, block, 0, st, p->d_tasks, t0, n_launch,
                                p->d_entries, p->d_task_rows, B, b_bytes, row_bytes, C, ldc, p->d_partial, d,
                                alpha, beta, wide_flags, slope, p->d_stamps, tpw > 1 ? p->round_tasks : n_launch);
         else if (vec2)

@@ -22,7 +22,7 @@ WIDTHS = [1, 2, 3, 4, 7, 8, 12, 16, 24, 31, 32, 33, 40, 41, 44, 47, 48, 49, 63, 
           129, 130, 132, 192, 200, 255, 256, 257, 300, 512, 608]
 KNOBS = ["MGGCN_SPMM_PERMUTE_COLUMNS", "MGGCN_SPMM_SWEEP_MIN_NNZ", "MGGCN_SPMM_PANEL_ROWS", "MGGCN_SPMM_PANEL_ROWS_NARROW",
          "MGGCN_SPMM_SLICE_ROWS", "MGGCN_SPMM_SWEEP_MIN_RUN_X10", "MGGCN_SPMM_ALGO", "MGGCN_SPMM_SWEEP_ROWS_PER_TASK",
-         "MGGCN_SPMM_TASKS_PER_WAVE"]
+         "MGGCN_SPMM_TASKS_PER_WAVE", "MGGCN_SPMM_FAST_PAIRS"]
 
 
 def random_graph(rng):
@@ -70,6 +70,7 @@ def random_form(rng):
             os.environ["MGGCN_SPMM_SWEEP_ROWS_PER_TASK"] = str(int(rng.choice([1, 4, 8, 16])))
         if rng.random() < 0.2:
             os.environ["MGGCN_SPMM_TASKS_PER_WAVE"] = str(int(rng.choice([2, 3])))
+        os.environ["MGGCN_SPMM_FAST_PAIRS"] = str(int(rng.integers(0, 2)))
     elif form == "rowsplit":
         os.environ["MGGCN_SPMM_ALGO"] = "rowsplit"
     return form, {k: os.environ[k] for k in KNOBS if k in os.environ}

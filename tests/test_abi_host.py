@@ -238,7 +238,7 @@ def test_reserved_accumulator_registers_are_left_alone_by_the_compiler(tmp_path)
         assert bodies, fam
         for name, body in bodies:
             assert {int(x) for x in re.findall(r"s_setprio (\d)", body)} == {0, 1, 2, 3}, name
-    # metadata of EVERY instantiation (pair + quad_lds<4|8|12|16>): 128 VGPRs, no AGPRs (a spill of the
+    # metadata of EVERY instantiation (pair<general|FAST> + quad_lds<4|8|12|16>): 128 VGPRs, no AGPRs (a spill of the
     # reserved planes would go there first), no scratch
     meta = text[text.index("amdhsa.kernels"):]
     blocks = [b for b in re.split(r"\n\s*- \.agpr_count:", "\n" + meta)[1:]]
@@ -252,7 +252,7 @@ def test_reserved_accumulator_registers_are_left_alone_by_the_compiler(tmp_path)
         assert re.search(r"\.agpr_count:\s+0\b", blk), (nm.group(1), blk[:400])
         assert re.search(r"\.vgpr_count:\s+128\b", blk), (nm.group(1), blk[:400])
         assert re.search(r"\.private_segment_fixed_size:\s+0\b", blk), (nm.group(1), blk[:400])
-    assert checked == 5, checked
+    assert checked == 6, checked
 
 
 def _longest_store_run(body: str, store_re: str) -> int:

@@ -319,12 +319,15 @@ def test_adam_fused_equals_chain_equals_oracle(pkg, oracle, ctx):
 
 
 # ---- column-panel sweep form of the SpMM (spmm_sweep.hip) ---------------------------------
-@pytest.fixture(params=[False, True], ids=["columns-as-given", "columns-permuted"])
+@pytest.fixture(params=["as-given", "permuted", "general"], ids=["columns-as-given", "columns-permuted", "general-pair-kernel"])
 def force_sweep(monkeypatch, request):
     """Small test matrices would fall back to the row-split kernels: force the sweep form
     and a tiny panel so that the (panel, row) ordering of the entry streams is exercised.
-    Second variant: the plan's internal column permutation (what a vertex order with locality triggers) forced on."""
-    monkeypatch.setenv("MGGCN_SPMM_PERMUTE_COLUMNS", "1" if request.param else "0")
+    Second variant: the plan's internal column permutation (what a vertex order with locality triggers) forced on.
+    Third: power-of-two pitches (d = 128, 256) through the general pair kernel instead of its FAST instance."""
+    monkeypatch.setenv("MGGCN_SPMM_PERMUTE_COLUMNS", "1" if request.param == "permuted" else "0")
+    if request.param == "general":
+        monkeypatch.setenv("MGGCN_SPMM_FAST_PAIRS", "0")
     monkeypatch.setenv("MGGCN_SPMM_SWEEP_MIN_NNZ", "1")
     monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS", "64")
     monkeypatch.setenv("MGGCN_SPMM_PANEL_ROWS_NARROW", "96")
