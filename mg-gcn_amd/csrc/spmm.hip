@@ -469,8 +469,8 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
                 std::swap(pi[c], pi[(uint32_t)(z % (c + 1))]);
             }
             for (uint32_t c = 0; c < n_cols; c++) src_row[pi[c]] = c;
-            const uint64_t nz0 = host_indptr[0], nz1 = host_indptr[n_rows];
-            permuted_indices.resize(nz1);                           // indexed like host_indices (offset nz0 kept)
+            const uint64_t nz1 = host_indptr[n_rows];
+            permuted_indices.resize(nz1);                           // indexed like host_indices (the offset host_indptr[0] kept)
             {
                 const uint32_t *src = host_indices;
                 plan_rows_parallel(n_rows, host_indptr, [&](unsigned, uint32_t r0, uint32_t r1) {
