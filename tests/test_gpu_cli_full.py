@@ -9,7 +9,7 @@
   C3' the one-process-per-GPU Python form: 4 `gloo` ranks on the card (the box allows 6 GPU processes), every rank
       loading only its rows of the files (dist.load_rank_local), K-piece all-gather schedule.
 
-Both Reddit stand-ins (tests/conftest.py): the SURVEY.md 8(d) one and the symmetric one.  Epoch-0 loss against
+The SURVEY.md 8(d) Reddit stand-in (tests/conftest.py; the symmetric one runs at full size in tests/test_gpu_configs.py).  Epoch-0 loss against
 the CPU oracle (exact-accumulation twin, pinned in tests/test_oracle_kat.py) at 1e-4; for P > 1 the oracle runs with the class count
 padded to a multiple of P (src/main.cpp:135) -- the row-partitioned model computes the same function, regrouped.
 The CLI's own per-epoch seconds are printed (pytest -s) and bounded loosely; bench.py reports them as `cli_epoch_ms`."""
@@ -65,7 +65,12 @@ def _check_loss(got, oracle, data, classes):
     assert abs(got[2] - want["acc"]) <= 8.0 / data["n"], (got, want["acc"])
 
 
-def test_cli_c2_full_reddit(oracle, reddit_any, reddit_dirs):
+def test_cli_c2_full_reddit(pkg, oracle, reddit_dirs):
+    # the SURVEY 8(d) stand-in.  (The symmetric one goes through the same kernels at full size in tests/test_gpu_configs.py;
+    # the second 35 s of CLI runs on it that this file held bought nothing the suite does not already hold -- the suite's
+    # wall time is a budget too.)
+    from conftest import reddit_standin
+    reddit_any = reddit_standin(pkg, "asym")
     d = reddit_dirs(reddit_any["kind"])
     r = _run(["-E", "6", "train", d] + HIDDEN, cwd=reddit_dirs.base)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -83,7 +88,7 @@ def test_cli_c2_full_reddit(oracle, reddit_any, reddit_dirs):
         assert re.search(rf"^5_0_{name}:", text, re.M), name
 
 
-@pytest.mark.parametrize("kind,mode", [("asym", "allgather"), ("asym", "rounds"), ("sym", "allgather")])
+@pytest.mark.parametrize("kind,mode", [("asym", "allgather"), ("asym", "rounds")])
 def test_cli_c3_p8_oversubscribed(pkg, oracle, reddit_dirs, kind, mode):
     from conftest import reddit_standin
     data = reddit_standin(pkg, kind)
