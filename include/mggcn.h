@@ -113,7 +113,9 @@ void mggcn_memset_zero(void *dst, size_t bytes, mggcn_stream_t stream);
  * PLAN owns mutable device scratch (partial-sum slots of sliced rows, the re-pitched copy of B of the narrow
  * form): one plan may be in flight on ONE stream at a time.  Calls on the same stream are ordered and safe;
  * to multiply by the same matrix on two streams concurrently, build two plans.  (mggcn_abssum_f32 keeps its
- * reduction scratch per stream: concurrent sums on different streams are safe.) */
+ * reduction scratch per stream: concurrent sums on different streams are safe.)
+ * Plan CREATION is re-entrant: several host threads may build plans at the same time (each thread makes its target
+ * device current first, mggcn_set_device) -- the host layers build a model's four plans side by side that way. */
 typedef struct mggcn_spmm_plan mggcn_spmm_plan;
 
 mggcn_spmm_plan *mggcn_spmm_plan_create(uint32_t n_rows, uint32_t n_cols,
