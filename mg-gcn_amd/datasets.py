@@ -449,6 +449,49 @@ def comm_volume_matrix(indptr, indices, P: int) -> np.ndarray:
     return L
 
 
+def adjacency_from_edges(src, dst, n: Optional[int] = None, weights=None, symmetric: bool = True):
+    """Edge list -> scipy CSR adjacency (the step in front of prepare_dataset when the graph comes as pairs, e.g. an OGB
+    `edge_index` or a text file of "u v" lines; the reference goes through DGL for this, test/data/prep.py:128-146).
+    ``symmetric``: both directions of every edge (prep.py builds its graphs undirected: dgl.to_bidirected, :137);
+    repeated pairs collapse to ONE entry of weight 1 (or of the summed ``weights``; with ``symmetric`` the larger of the two
+    directions), self-pairs are dropped -- prepare_dataset adds the self-loops (prep.py:113)."""
+    import scipy.sparse as sp
+    src = np.asarray(src, dtype=np.int64).reshape(-1)
+    dst = np.asarray(dst, dtype=np.int64).reshape(-1)
+    if src.shape != dst.shape:
+        raise ValueError("src and dst must have the same length")
+    if src.size and (src.min() < 0 or dst.min() < 0):
+        raise ValueError("negative vertex id")
+    n = int(max(src.max(initial=-1), dst.max(initial=-1)) + 1) if n is None else int(n)
+    if src.size and max(src.max(), dst.max()) >= n:
+        raise ValueError("vertex id out of range")
+    w = np.ones(src.shape[0], dtype=np.float64) if weights is None else np.asarray(weights, dtype=np.float64).reshape(-1)
+    keep = src != dst
+    src, dst, w = src[keep], dst[keep], w[keep]
+    A = sp.coo_matrix((w, (src, dst)), shape=(n, n)).tocsr()          # duplicates are summed here
+    if symmetric:
+        A = A.maximum(A.T)                                             # weighted: the larger of the two directions
+    if weights is None:
+        A.data[:] = 1.0
+    A = sp.csr_matrix(A, dtype=np.float32)
+    A.sort_indices()
+    return A
+
+
+def read_edge_list(path: str):
+    """(src, dst) from a text file of "u v" lines ('#' comments; extra columns ignored) or from an .npy file holding an
+    array of shape [E, 2] or [2, E] (the OGB `edge_index` layout)."""
+    if path.endswith(".npy"):
+        e = np.load(path, allow_pickle=False)
+        if e.ndim != 2 or 2 not in e.shape:
+            raise ValueError("edge array must be [E, 2] or [2, E]")
+        if e.shape[1] == 2:                                            # [E, 2] (a 2 x 2 array is read this way)
+            e = e.T
+        return np.asarray(e[0], dtype=np.int64), np.asarray(e[1], dtype=np.int64)
+    e = np.loadtxt(path, dtype=np.int64, comments="#", usecols=(0, 1), ndmin=2)
+    return e[:, 0], e[:, 1]
+
+
 def prepare_dataset(dirname: str, adj, features, labels, sets=None, P: int = 8, seed: int = 0,
                     permutation=None, partitioner=None) -> str:
     """adj: scipy sparse (n x n) or (indptr, indices, data) CSR triple; features [n x F];

@@ -378,3 +378,67 @@ def test_traffic_counters_belong_to_the_kernels_in_the_tree():
     assert j.get("kernel_source_sha") == bench.spmm_kernel_sha(), \
         "profiles/spmm_hbm_traffic.json is older than csrc/spmm*.hip: run profiles/collect.sh + summarize.py again"
     assert os.path.exists(os.path.join(ROOT, j["source"]))
+
+
+def test_edge_list_to_dataset_files(pkg, tmp_path):
+    """the step in front of the on-disk format when a graph comes as pairs (OGB edge_index, a text file): edge list ->
+    adjacency (both directions, duplicates collapsed, self-pairs dropped) -> prepare_dataset (padding, self-loops) -> the
+    reference's files -> read back (test/data/prep.py:128-146 does this through DGL)."""
+    ds = pkg.datasets
+    src = np.array([0, 1, 1, 2, 4, 4, 0, 3], dtype=np.int64)
+    dst = np.array([1, 0, 2, 2, 0, 0, 4, 5], dtype=np.int64)               # (1,0) repeats (0,1); (2,2) is a self-pair; (4,0) twice
+    A = ds.adjacency_from_edges(src, dst, n=6)
+    want = np.zeros((6, 6), np.float32)
+    for u, v in [(0, 1), (1, 2), (0, 4), (3, 5)]:
+        want[u, v] = want[v, u] = 1.0
+    np.testing.assert_array_equal(A.toarray(), want)
+    D = ds.adjacency_from_edges(src, dst, n=6, symmetric=False).toarray()
+    assert D[4, 0] == 1.0 and D[0, 4] == 1.0 and D[3, 5] == 1.0 and D[5, 3] == 0.0 and D[2, 2] == 0.0
+    with pytest.raises(ValueError):
+        ds.adjacency_from_edges([0, 7], [1, 2], n=6)
+    # text and .npy forms of the same list
+    txt = tmp_path / "edges.txt"
+    txt.write_text("# u v\n" + "\n".join(f"{u} {v}" for u, v in zip(src, dst)) + "\n")
+    np.save(tmp_path / "edges.npy", np.stack([src, dst]))                   # [2, E], the OGB layout
+    for path in (str(txt), str(tmp_path / "edges.npy")):
+        s2, d2 = ds.read_edge_list(path)
+        np.testing.assert_array_equal(s2, src)
+        np.testing.assert_array_equal(d2, dst)
+    X = np.arange(18, dtype=np.float32).reshape(6, 3)
+    Y = np.array([0, 1, 2, 0, 1, 2])
+    out = ds.prepare_dataset(str(tmp_path / "g"), A, X, Y, P=8, seed=0)
+    (ip, ix, dv, n, m), X2, Y2, _ = ds.read_dataset(out)
+    assert (n, m) == (8, 8) and X2.shape == (8, 8) and len(ix) == 8 + 8      # padded to a multiple of P; 8 edges + 8 self-loops
+    dense = np.zeros((8, 8), np.float32)
+    for r in range(8):
+        dense[r, ix[ip[r]:ip[r + 1]]] = dv[ip[r]:ip[r + 1]]
+    full = np.zeros((8, 8), np.float32)
+    full[:6, :6] = want
+    np.testing.assert_array_equal(dense, full + np.eye(8, dtype=np.float32))
+    np.testing.assert_array_equal(X2[:6, :3], X)
+    np.testing.assert_array_equal(Y2[:6, 0], Y)
+
+
+def test_prep_command_line(pkg, tmp_path):
+    """mg-gcn_amd/prep.py: edge list + .npy features / labels -> the files `mg_gcn train <dir>` reads (the role of the
+    reference's test/data/prep.py, without DGL / OGB / network)."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(0)
+    n, E = 50, 300
+    e = rng.integers(0, n, size=(E, 2))
+    np.save(tmp_path / "e.npy", e)
+    np.save(tmp_path / "x.npy", rng.standard_normal((n, 5)).astype(np.float32))
+    np.save(tmp_path / "y.npy", rng.integers(0, 4, size=n))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "mg-gcn_amd", "prep.py"), "--edges", str(tmp_path / "e.npy"),
+                        "--features", str(tmp_path / "x.npy"), "--labels", str(tmp_path / "y.npy"), "--out", str(tmp_path / "data" / "g"),
+                        "-P", "4", "--seed", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout.splitlines()[0]
+    assert out == str(tmp_path / "data" / "permuted" / "g") and "halo rows per exchange" in r.stdout
+    (ip, ix, dv, nn, m), X, Y, S = pkg.datasets.read_dataset(out)
+    assert nn == m == 52 and X.shape == (52, 8) and Y.shape == (52, 1)           # padded to multiples of P = 4
+    A = pkg.datasets.adjacency_from_edges(e[:, 0], e[:, 1], n=n)
+    assert len(ix) == A.nnz + 52                                                # + one self-loop per (padded) vertex
+    rows = np.repeat(np.arange(52), np.diff(ip.astype(np.int64)))
+    assert set(zip(rows.tolist(), ix.tolist())) == set(zip(ix.tolist(), rows.tolist()))   # pattern stays symmetric

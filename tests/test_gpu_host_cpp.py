@@ -155,3 +155,35 @@ def test_cli_hoisted_first_aggregation_matches_the_plain_run(pkg, oracle, tmp_pa
         assert abs(got[hoist][0][1] - want[0]) <= 1e-4 * want[0]
         assert got[hoist][2][1] < got[hoist][0][1]
     assert abs(got["1"][0][1] - got["0"][0][1]) <= 1e-4 * got["0"][0][1]
+
+
+def test_prep_files_train_through_the_cli(pkg, oracle, tmp_path):
+    """edge list -> mg-gcn_amd/prep.py -> `mg_gcn -P 2 -R 1 train <dir>`: the files the prep front writes (padded, self-loops,
+    permuted) are what the CLI reads -- header line, class count and feature width as written, epoch-0 loss as the oracle
+    computes it from the SAME files (test/data/prep.py + src/main.cpp:82-98 end to end)."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    n, E, F, C = 600, 9000, 21, 5
+    e = rng.integers(0, n, size=(2, E))
+    np.save(tmp_path / "e.npy", e)
+    np.save(tmp_path / "x.npy", rng.standard_normal((n, F)).astype(np.float32))
+    y = rng.integers(0, C, size=n); y[0] = C - 1
+    np.save(tmp_path / "y.npy", y)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "mg-gcn_amd", "prep.py"), "--edges", str(tmp_path / "e.npy"),
+                        "--features", str(tmp_path / "x.npy"), "--labels", str(tmp_path / "y.npy"),
+                        "--out", str(tmp_path / "data" / "g"), "-P", "8", "--seed", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = r.stdout.splitlines()[0]
+    (ip, ix, dv, nn, _), X, Y, _ = pkg.datasets.read_dataset(d)
+    assert nn == 600 and X.shape[1] == 24                                   # 600 = 8 * 75 already; 21 features -> 24
+    r = _run([os.path.join(BIN, "mg_gcn"), "-P", "2", "-R", "1", "-E", "2", "train", d, "2", "16", "16"], cwd=str(tmp_path),
+             env={"MGGCN_OVERSUBSCRIBE": "1"})
+    assert r.returncode == 0, r.stderr
+    lines = r.stderr.strip().splitlines()
+    assert lines[0] == f"{nn} {len(ix)}" and lines[1] == f"num_labels = {C}" and lines[2] == "feature size = 24"
+    got = [tuple(float(x) for x in ln.split()) for ln in lines[3:5]]
+    O = oracle.DistGcn(oracle.Csr(ip, ix, dv, nn), [24, 16, 16, C], 2)      # classes padded to a multiple of P inside
+    want = O.train_forward(X, Y)
+    assert abs(got[0][1] - want[0]) <= 1e-4 * want[0] and got[1][1] < got[0][1]
