@@ -16,7 +16,12 @@ vertex permutation), features N(0,1) [n x 608], 41 uniform classes.
 
 One process per GPU; N > 1 shards the vertices (1D row partition) and exchanges
 feature shards over RCCL.  Total work is fixed as N grows -> "scaling": "strong".
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  Plain `python bench.py --gpus N` (no launcher, WORLD_SIZE
+unset) starts the N ranks itself -- torch.distributed.run as a CHILD process, before
+this process has touched the GPU -- and relays rank 0's line and the children's exit code:
+one command, like the reference (`mg_gcn -P N ...`, README.md:44).  At N > 1 the line also
+carries the drop-in CLI's own epoch time on the same files (`cli_epoch_ms` and friends: the
+single-process C++ form, one enqueue thread per GPU, RCCL and peer-copy transports).
 """
 from __future__ import annotations
 
@@ -60,38 +65,126 @@ def spmm_kernel_sha():
     return h.hexdigest()[:16]
 
 
-def run_cli_epochs(pkg, indptr, indices, data, X, Y, hidden, epochs=8):
-    """`mg_gcn -E <epochs> train <dir> <k> <h...>` (the reference's interface, src/main.cpp:113-131) on the same
-    workload, written in the reference's on-disk format: median of the CLI's OWN per-epoch seconds (epochs 2..),
-    and its set-up (process start to the end of epoch 0 minus one epoch: file load, normalise / transpose, plans)."""
-    import shutil
+def cli_leg(dataset_dir, cwd, hidden, flags=(), env=None, epochs=8, timeout=300):
+    """One run of `mg_gcn [flags] -E <epochs> train <dir> <k> <h...>` (the reference's interface, src/main.cpp:113-131 /
+    :134-170): median of the CLI's OWN per-epoch seconds (epochs 2..), its set-up (process start to the end of epoch 0
+    minus one epoch: file load, normalise / transpose, partition, plans), the first epoch's loss and -- from the
+    MGGCN_TIMING lines -- the transport and enqueue mode the distributed classes ran with.  The child runs in its own
+    session and is killed as a group when it exceeds `timeout` (a first multi-GPU contact must not cost the line)."""
+    import signal
     import subprocess
-    import tempfile
     exe = os.path.join(ROOT, "mg-gcn_amd", "bin", "mg_gcn")
     if not os.path.exists(exe):
         return None
+    e = dict(os.environ)
+    e.update(env or {})
+    e["MGGCN_TIMING"] = "1"
+    cmd = [exe] + list(flags) + ["-E", str(epochs), "train", dataset_dir, str(len(hidden))] + [str(h) for h in hidden]
+    t = time.perf_counter()
+    proc = subprocess.Popen(cmd, cwd=cwd, env=e, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        _, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        proc.wait()
+        return {"error": f"timeout after {timeout} s"}
+    wall = time.perf_counter() - t
+    if proc.returncode != 0:
+        return {"error": err[-300:]}
+    ep, info = [], {}
+    for ln in err.splitlines():
+        t4 = ln.split()
+        if len(t4) == 4 and t4[0].isdigit():
+            ep.append((float(t4[1]), float(t4[3])))
+        elif ln.startswith("[mggcn timing] transport ") and len(t4) >= 6:
+            info = {"transport": t4[3], "enqueue_threads": int(t4[5])}
+    if len(ep) < 3:
+        return {"error": "no epoch lines"}
+    med = float(np.median([x[1] for x in ep[2:]]))
+    out = {"epoch_ms": round(med * 1e3, 4), "setup_s": round(wall - sum(x[1] for x in ep[1:]) - med, 2),
+           "loss_first": ep[0][0], "epochs": len(ep)}
+    out.update(info)
+    return out
+
+
+def run_cli_epochs(pkg, indptr, indices, data, X, Y, hidden, epochs=8):
+    """N = 1: the same workload written in the reference's on-disk format and run through `mg_gcn train ...`."""
+    import shutil
+    import tempfile
     tmp = tempfile.mkdtemp(prefix="mggcn_bench_cli_")
     try:
         d = os.path.join(tmp, "permuted", "bench")
         pkg.datasets.write_dataset(d, indptr, indices, data, X, Y)
-        t = time.perf_counter()
-        r = subprocess.run([exe, "-E", str(epochs), "train", d, str(len(hidden))] + [str(h) for h in hidden],
-                           cwd=tmp, capture_output=True, text=True, timeout=600)
-        wall = time.perf_counter() - t
-        if r.returncode != 0:
-            return {"error": r.stderr[-300:]}
-        ep = []
-        for ln in r.stderr.splitlines():
-            t4 = ln.split()
-            if len(t4) == 4 and t4[0].isdigit():
-                ep.append((float(t4[1]), float(t4[3])))
-        if len(ep) < 3:
-            return {"error": "no epoch lines"}
-        med = float(np.median([e[1] for e in ep[2:]]))
-        return {"cli_epoch_ms": round(med * 1e3, 4), "cli_setup_s": round(wall - sum(e[1] for e in ep[1:]) - med, 2),
-                "cli_loss_first": ep[0][0], "cli_epochs": len(ep)}
+        r = cli_leg(d, tmp, hidden, epochs=epochs, timeout=600)
+        if r is None or "error" in r:
+            return r
+        return {"cli_epoch_ms": r["epoch_ms"], "cli_setup_s": r["setup_s"], "cli_loss_first": r["loss_first"], "cli_epochs": r["epochs"]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def run_cli_multi_gpu(dataset_dir, P, hidden, mode, overlap, rehearsal, epochs=8):
+    """N > 1: the PRODUCT PATH of north_star -- `mg_gcn -P N -R 1 train <dir> ...`, one process driving the N GPUs
+    (src/main.cpp:134-170) -- on the files the Python ranks just trained on, after they have let go of the GPUs.  Legs:
+      default  one enqueue thread per GPU, RCCL (grouped calls become per-thread calls)        -> cli_epoch_ms, cli_transport, ...
+      p2p      same, exchange by peer copies on the copy engines (no compute unit taken from the SpMM)  -> cli_p2p_*
+      serial   the reference's process model: ONE host thread issues every GPU's work, RCCL    -> cli_serial_*
+    Each leg is bounded (own session, killed on timeout); a failed leg reports its error and the next one still runs."""
+    import tempfile
+    cwd = tempfile.mkdtemp(prefix="mggcn_bench_cli_")
+    base = {"MGGCN_DIST_MODE": mode}
+    if rehearsal:
+        base["MGGCN_OVERSUBSCRIBE"] = "1"                      # N ranks wrapped over the one GPU: peer-copy transport only
+    flags = ["-P", str(P), "-R", "1"] + ([] if overlap else ["-S", "x"])
+    threads = {"MGGCN_ENQUEUE_THREADS": "1"}
+    legs = [("cli", threads)] if rehearsal else [("cli", threads), ("cli_p2p", dict(threads, MGGCN_COMM_TRANSPORT="p2p")),
+                                                 ("cli_serial", {"MGGCN_ENQUEUE_THREADS": "0"})]
+    out = {}
+    try:
+        for key, extra in legs:
+            r = cli_leg(dataset_dir, cwd, hidden, flags, dict(base, **extra), epochs=epochs, timeout=240)
+            if r is None:
+                return None
+            for k, v in r.items():
+                out[f"{key}_{k}"] = v
+    finally:
+        import shutil
+        shutil.rmtree(cwd, ignore_errors=True)
+    return out
+
+
+def multi_gpu_env(env, world):
+    """Environment every multi-process / multi-GPU leg needs (set here, not left to the caller):
+      HSA_ENABLE_IPC_MODE_LEGACY=0  the host driver of this pool only supports dmabuf IPC; without it RCCL's (and
+                                    torch's) cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`
+      MGGCN_HOST_THREADS            the N ranks share one host: every rank builds up to four SpMM plans side by side and
+                                    each plan builder starts MGGCN_HOST_THREADS threads (default: every core it sees)"""
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "MGGCN_HOST_THREADS" not in env:
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 8
+        env["MGGCN_HOST_THREADS"] = str(max(2, min(16, avail // (4 * max(world, 1)) or 2)))
+    return env
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run the N ranks as a child `python -m torch.distributed.run`
+    (this process has made no GPU call and makes none), pass rank 0's JSON line through, exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = multi_gpu_env(dict(os.environ), n)
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)              # stdout / stderr are inherited: the line reaches our stdout as is
 
 
 def main():
@@ -116,16 +209,12 @@ def main():
                     help="HEADLINE workload = the symmetric stand-in (pattern A = A^T like the real Reddit); manual mode")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     if args.chunks > 0:
         os.environ["MGGCN_DIST_CHUNKS"] = str(args.chunks)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "MGGCN_HOST_THREADS" not in os.environ:
-        # N ranks share this host: every rank builds up to four SpMM plans side by side and each plan builder starts
-        # MGGCN_HOST_THREADS threads (default: all the cores it can see) -- keep the node's total in the hundreds
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 8
-        os.environ["MGGCN_HOST_THREADS"] = str(max(2, min(16, avail // (4 * int(os.environ["WORLD_SIZE"])) or 2)))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        multi_gpu_env(os.environ, int(os.environ["WORLD_SIZE"]))
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to
     # stdout when its first communicator comes up; gloo prints its rank table): everything this process writes to
     # file descriptor 1 from here on goes to stderr, and the JSON line goes to the real stdout at the end.
@@ -137,10 +226,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if args.gpus > 1 and world == 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world                          # under a launcher the launcher's world size is the truth
     P = world
     pkg = ge.load_package()
     pkg._lib.require_gpu()                     # loud: there is no CPU path
@@ -207,9 +293,7 @@ def main():
             del indptr, indices, data, X, Y
         dist.barrier()
         Ad, A_Td, Xd, Yd, info = D.load_rank_local(dctx, tmp)
-        dist.barrier()
-        if rank == 0:
-            shutil.rmtree(tmp, ignore_errors=True)
+        dist.barrier()                                   # (the files stay: the CLI legs read them after the timed epochs)
         n = info["n"]
         nnz = int(dctx.host_all_reduce(np.array([info["nnz_local"]], dtype=np.int64))[0])
         sizes = [info["features"]] + list(args.hidden) + [(info["num_labels"] + P - 1) // P * P]   # src/main.cpp:135
@@ -373,8 +457,23 @@ def main():
                 abs(out["cpu_baseline"]["loss"] - losses[0]) <= 1e-4 * abs(out["cpu_baseline"]["loss"]))
 
     if multi:
+        # the ranks let go of the GPUs (model, plans, shards), then rank 0 alone runs the drop-in CLI on the same files
+        G = Ad = A_Td = Xd = Yd = None
+        epoch = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0:
+            try:
+                if not args.no_extras and args.workload == "reddit_like":
+                    cli = run_cli_multi_gpu(tmp, P, args.hidden, args.mode, not args.no_overlap, rehearsal)
+                    if cli:
+                        out.update(cli)
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

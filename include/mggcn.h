@@ -131,6 +131,10 @@ mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t n_cols,
                                             const uint32_t *host_indptr, const uint32_t *host_indices,
                                             const float *host_values, uint32_t max_d, uint32_t d_hint);
 void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan);
+/* A caller that builds n plans side by side (one host thread each) says so before it starts: every builder then threads
+ * its own passes over cores / n instead of all the cores (MGGCN_HOST_THREADS in the environment still wins).  Set it back
+ * to 1 afterwards.  Process-wide. */
+void mggcn_spmm_plan_concurrent_builders(uint32_t n);
 /* introspection (tests, DESIGN.md figures) */
 uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan);
 uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan);

@@ -10,16 +10,25 @@
  * plus the exchange the MI355X build prefers: ONE all-gather of the row shards instead of P
  * broadcasts (every GPU pushes to its 7 xGMI peers at once).
  *
- * Like the reference this is the one-host-thread model: every function takes one buffer and
- * one stream PER GPU (arrays of length P, index = device ordinal in the communicator) and
- * issues the P per-communicator calls inside one ncclGroupStart/End.  Enqueue-only; fail-fast
- * (message + exit) like CHECK_NCCL (src/mg_gcn.hpp:60-68).  fp32 payloads only.
+ * Every function takes one buffer and one stream PER GPU (arrays of length P, index = device
+ * ordinal in the communicator).  Enqueue-only; fail-fast (message + exit) like CHECK_NCCL
+ * (src/mg_gcn.hpp:60-68).  fp32 payloads only.
  *
  * Two transports (picked at init, see mggcn_comm_transport): "rccl" -- one communicator per GPU,
- * the reference's pattern; "p2p" -- event-ordered device-to-device copies pulled by every
- * receiver on its own stream (hipMemcpyPeerAsync over xGMI, or same-device copies), sums formed in
- * rank order on every GPU.  p2p is selected when two ranks share a GPU (RCCL refuses that: this is
- * how the P > 1 schedules run on a one-GPU box) or with MGGCN_COMM_TRANSPORT=p2p.
+ * the reference's pattern; "p2p" -- device-to-device copies (hipMemcpyPeerAsync over xGMI: copy
+ * engines, no compute unit is taken from the SpMM running meanwhile; same-device copies when ranks
+ * share a GPU) ordered by events PER PAIR: a receiver pulls a sender's piece as soon as that
+ * sender's stream has produced it, every pull on its own per-peer stream; sums formed in rank order
+ * on every GPU.  p2p is selected when two ranks share a GPU (RCCL refuses that: this is how the
+ * P > 1 schedules run on a one-GPU box) or with MGGCN_COMM_TRANSPORT=p2p.
+ *
+ * Two families of entry points over the same transports:
+ *   all ranks   (the reference's one-host-thread model) one call takes one buffer and one stream PER
+ *               GPU and issues the P per-communicator calls inside one ncclGroupStart/End;
+ *   one rank    (`_rank_`) the same arrays plus `rank`: only that rank's share is issued, from that
+ *               rank's enqueue thread (host/enqueue.hpp: one thread per GPU).  All P ranks must make
+ *               the same sequence of calls; a rank's call may block on the host until its peers have
+ *               issued theirs (p2p: until their `ready` events are recorded), never on the device.
  *
  * Kept in its own library so that a process that already hosts an RCCL (e.g. PyTorch's
  * bundled one) never loads a second copy: the one-process-per-GPU host layer uses
@@ -45,6 +54,21 @@ int mggcn_comm_size(const mggcn_comm *comm);
 /* "rccl" or "p2p" */
 const char *mggcn_comm_transport(const mggcn_comm *comm);
 
+/* Exchange flags (p2p transport; rccl ignores them), mggcn_comm_set_exchange_flags:
+ *   MGGCN_COMM_DEFER_RELEASE  an exchange returns without making the streams wait for the READERS of what this rank
+ *                             sent (default: it waits, which is NCCL's contract -- the send buffer may be overwritten
+ *                             by later work on the stream).  The caller then calls mggcn_comm_release[_rank] on the
+ *                             stream that will overwrite the send buffers, before that work.  All-reduce never defers.
+ *   MGGCN_COMM_SKIP_SELF      all-gather: a rank's own piece is not copied into its receive buffer (the host layer's
+ *                             remote blocks never read it; one copy kernel fewer next to the SpMM) */
+#define MGGCN_COMM_DEFER_RELEASE 1u
+#define MGGCN_COMM_SKIP_SELF 2u
+void mggcn_comm_set_exchange_flags(mggcn_comm *comm, unsigned flags);
+/* streams[j] (resp. `stream` of `rank`) waits until every peer has read what rank j sent in the exchanges so far.
+ * No-op on the rccl transport and when nothing is outstanding. */
+void mggcn_comm_release(mggcn_comm *comm, const mggcn_stream_t *streams);
+void mggcn_comm_release_rank(mggcn_comm *comm, int rank, mggcn_stream_t stream);
+
 /* recv[j] <- send_root (count floats) on every GPU j; send_root lives on GPU `root`. */
 void mggcn_comm_broadcast_f32(mggcn_comm *comm, const float *send_root, float *const *recv, size_t count,
                               int root, const mggcn_stream_t *streams);
@@ -63,6 +87,17 @@ void mggcn_comm_alltoallv_displacements(int P, const size_t *counts, size_t *sdi
 /* bufs[j] <- sum_i bufs[i], in place, on every GPU j. */
 void mggcn_comm_allreduce_sum_f32(mggcn_comm *comm, float *const *bufs, size_t count,
                                   const mggcn_stream_t *streams);
+
+
+/* One rank's share of the collectives above (same arrays, all P entries valid; `stream` is that rank's stream). */
+void mggcn_comm_broadcast_rank_f32(mggcn_comm *comm, int rank, const float *send_root, float *const *recv,
+                                   size_t count, int root, mggcn_stream_t stream);
+void mggcn_comm_allgather_rank_f32(mggcn_comm *comm, int rank, const float *const *send, float *const *recv,
+                                   size_t count, mggcn_stream_t stream);
+void mggcn_comm_alltoallv_rank_f32(mggcn_comm *comm, int rank, const float *const *send, float *const *recv,
+                                   const size_t *counts, mggcn_stream_t stream);
+void mggcn_comm_allreduce_sum_rank_f32(mggcn_comm *comm, int rank, float *const *bufs, size_t count,
+                                       mggcn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -2,23 +2,51 @@
 // See include/mggcn_comm.h for the reference call sites this replaces.
 //
 // Two transports behind the same entry points:
-//   rccl  one RCCL communicator per GPU (ncclCommInitAll), every collective a group of P
-//         per-communicator calls -- the reference's NCCL pattern (src/dist_matrix.hpp:26-31,
-//         :458-467, :587-592).  Default when the P ranks sit on P different GPUs.
-//   p2p   plain device-to-device copies (hipMemcpyPeerAsync over xGMI, or same-device copies)
-//         ordered by events: every receiver PULLS the pieces it needs on its own stream once
-//         the senders' streams have produced them, and no sender runs on before every
-//         receiver has read its buffer.  Chosen automatically when two ranks share a GPU
-//         (RCCL refuses that) -- which is how the P > 1 schedules of the host layer are run
-//         on a one-GPU box -- or with MGGCN_COMM_TRANSPORT=p2p.  Sums are formed in rank
-//         order on every GPU: identical bits everywhere, like a ring all-reduce's result.
+//   rccl  one RCCL communicator per GPU (ncclCommInitAll).  The all-ranks entry points issue a
+//         group of P per-communicator calls from the calling thread -- the reference's NCCL
+//         pattern (src/dist_matrix.hpp:26-31, :458-467, :587-592); the per-rank entry points
+//         issue rank j's call from rank j's enqueue thread (one thread per device needs no
+//         group).  Default when the P ranks sit on P different GPUs.
+//   p2p   device-to-device copies (hipMemcpyPeerAsync over xGMI: copy engines, no compute
+//         unit is taken from the SpMM that runs meanwhile; same-device copies when ranks share
+//         a GPU) ordered by events, PER PAIR: receiver j pulls from sender i as soon as i's
+//         stream has produced the piece (`ready`), every pull on its own per-peer stream so
+//         that the seven links of a GPU work at once; nobody waits for a third rank.  A sender
+//         may overwrite what it sent once its readers are done: that wait is either issued
+//         right after the exchange (default: NCCL's contract) or deferred to an explicit
+//         mggcn_comm_release (MGGCN_COMM_DEFER_RELEASE: the host layer releases on the
+//         compute stream at the end of an SpMM, so a late rank delays nobody's SpMM over
+//         pieces that have landed).  Chosen automatically when two ranks share a GPU (RCCL
+//         refuses that) -- which is how the P > 1 schedules run on a one-GPU box -- or with
+//         MGGCN_COMM_TRANSPORT=p2p.  Sums are formed in rank order on every GPU: identical
+//         bits everywhere.
+//
+// Host-side protocol of the p2p transport (all ranks take part in every exchange, in the same
+// order; exchange number s = 1, 2, ...):
+//   begin(j)    record ready[j][s % R] on j's stream, publish ready_seq[j] = s
+//   pull(j)     for every sender i it reads: wait (host) until ready_seq[i] >= s, then make the
+//               pulling stream wait for ready[i][s % R]; copies; record done[j][s % R] on j's
+//               stream, publish done_seq[j] = s
+//   release(j)  wait (host) until done_seq[i] >= s_last for every other rank, make the given
+//               stream wait for done[i][s_last % R] (pulls of one rank run in order, so the
+//               latest `done` covers the earlier ones), publish released_seq[j]
+// The all-ranks entry points run begin for all ranks, then pull for all, then release: the host
+// waits are satisfied by construction.  The per-rank entry points run on P threads and the
+// sequence counters are what orders "event recorded" before "event waited for".  Event slots
+// are reused every R exchanges: a rank that is R / 2 exchanges behind with its releases
+// releases on the spot, so a slot is never re-recorded while somebody still has to wait for it.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <set>
+#include <thread>
 #include <vector>
 
 #include "comm_layout.h"
@@ -46,68 +74,198 @@
         }                                                                                        \
     } while (0)
 
+namespace {
+
+constexpr int kRing = 32;                      // event slots per rank (see the header comment)
+
+struct rank_state {
+    hipEvent_t ready[kRing] = {}, done[kRing] = {};
+    hipEvent_t fork = nullptr;                 // j's stream -> its per-peer streams
+    std::vector<hipStream_t> peer_stream;      // [i]: pulls from rank i (null: pull on j's own stream)
+    std::vector<hipEvent_t> peer_done;         // [i]
+    std::atomic<std::uint64_t> ready_seq{0}, done_seq{0}, released_seq{0};
+    std::uint64_t seq = 0;                     // exchanges begun; touched by the rank's caller only
+    float *scratch = nullptr;                  // all-reduce: P x count floats
+    std::size_t scratch_floats = 0;
+};
+
+}  // namespace
+
 struct mggcn_comm {
     std::vector<ncclComm_t> comms;      // rccl transport; empty for p2p
     std::vector<int> devices;
     bool p2p = false;
-    std::vector<hipEvent_t> ready, done;   // p2p: one pair per rank
-    std::vector<float *> scratch;          // p2p all-reduce: P x count floats per rank
-    std::vector<size_t> scratch_floats;
+    unsigned flags = 0;                 // MGGCN_COMM_DEFER_RELEASE | MGGCN_COMM_SKIP_SELF
+    std::vector<std::unique_ptr<rank_state>> rk;   // p2p
 };
 
 namespace {
 
 inline hipStream_t as_stream(mggcn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int size_of(const mggcn_comm *c) { return (int)c->devices.size(); }
 
-void copy_f32(const mggcn_comm *c, float *dst, int dst_rank, const float *src, int src_rank, size_t count,
-              hipStream_t st) {
+void require(bool ok, const char *what) {
+    if (ok) return;
+    std::fprintf(stderr, "MGGCN precondition failed: %s\n", what);
+    std::exit(EXIT_FAILURE);
+}
+
+// host wait for another rank's progress; a peer that never arrives is a protocol error (or a dead enqueue thread):
+// say so instead of hanging
+void await(const std::atomic<std::uint64_t> &counter, std::uint64_t value, const char *what, int me, int peer) {
+    if (counter.load(std::memory_order_acquire) >= value) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        if (counter.load(std::memory_order_acquire) >= value) return;
+        if (spins < 4096) continue;
+        std::this_thread::yield();
+        if ((spins & 0xffffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+            std::fprintf(stderr, "MGGCN comm: rank %d waited 120 s for rank %d to reach %s of exchange %llu (it is at %llu)\n", me, peer,
+                         what, (unsigned long long)value, (unsigned long long)counter.load());
+            std::exit(EXIT_FAILURE);
+        }
+    }
+}
+
+void copy_f32(const mggcn_comm *c, float *dst, int dst_rank, const float *src, int src_rank, size_t count, hipStream_t st) {
     if (!count) return;
     const int dd = c->devices[dst_rank], sd = c->devices[src_rank];
     if (dd == sd) CHECK_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToDevice, st));
     else CHECK_HIP(hipMemcpyPeerAsync(dst, dd, src, sd, count * sizeof(float), st));
 }
 
-// p2p skeleton: pull(j) enqueues rank j's copies on streams[j].  Before them stream j waits for
-// every rank's earlier work (the data is produced on those streams); after them no stream
-// proceeds until every rank has finished reading (the callers reuse their send buffers).
-template <typename F>
-void p2p_exchange(mggcn_comm *c, const mggcn_stream_t *streams, F &&pull) {
-    const int P = (int)c->devices.size();
-    for (int i = 0; i < P; i++) {
-        CHECK_HIP(hipSetDevice(c->devices[i]));
-        CHECK_HIP(hipEventRecord(c->ready[i], as_stream(streams[i])));
+void p2p_release_rank(mggcn_comm *c, int j, hipStream_t st) {
+    rank_state &me = *c->rk[j];
+    const std::uint64_t s = me.seq;
+    if (me.released_seq.load(std::memory_order_relaxed) >= s) return;
+    for (int i = 0; i < size_of(c); i++) {
+        if (i == j) continue;
+        await(c->rk[i]->done_seq, s, "the end", j, i);
+        CHECK_HIP(hipStreamWaitEvent(st, c->rk[i]->done[s % kRing], 0));
     }
-    for (int j = 0; j < P; j++) {
-        CHECK_HIP(hipSetDevice(c->devices[j]));
-        for (int i = 0; i < P; i++)
-            if (i != j) CHECK_HIP(hipStreamWaitEvent(as_stream(streams[j]), c->ready[i], 0));
-        pull(j);
-        CHECK_HIP(hipEventRecord(c->done[j], as_stream(streams[j])));
+    me.released_seq.store(s, std::memory_order_release);
+}
+
+// starts exchange number (returned) for rank j: everything queued on `st` so far is what the peers may read
+std::uint64_t p2p_begin(mggcn_comm *c, int j, hipStream_t st) {
+    rank_state &me = *c->rk[j];
+    CHECK_HIP(hipSetDevice(c->devices[j]));
+    if (me.seq - me.released_seq.load(std::memory_order_relaxed) >= (std::uint64_t)kRing / 2) p2p_release_rank(c, j, st);
+    const std::uint64_t s = ++me.seq;
+    if (s > (std::uint64_t)kRing)                                  // slot s % R was last used by exchange s - R
+        for (int i = 0; i < size_of(c); i++)
+            if (i != j) {
+                await(c->rk[i]->done_seq, s - kRing, "the end", j, i);              // i has waited for my ready[s - R] ...
+                await(c->rk[i]->released_seq, s - kRing, "the release", j, i);      // ... and for my done[s - R]
+            }
+    CHECK_HIP(hipEventRecord(me.ready[s % kRing], st));
+    me.ready_seq.store(s, std::memory_order_release);
+    return s;
+}
+
+struct pull_item { int src; float *dst; const float *from; size_t count; };
+
+// rank j's copies of exchange s: each from its sender as soon as that sender is ready
+void p2p_pull(mggcn_comm *c, int j, std::uint64_t s, hipStream_t st, const std::vector<pull_item> &items) {
+    rank_state &me = *c->rk[j];
+    CHECK_HIP(hipSetDevice(c->devices[j]));
+    bool forked = false;
+    std::vector<char> joined(size_of(c), 0);
+    for (const auto &it : items) {
+        if (!it.count) continue;
+        if (it.src == j) {                                         // my own piece: nobody to wait for
+            copy_f32(c, it.dst, j, it.from, j, it.count, st);
+            continue;
+        }
+        await(c->rk[it.src]->ready_seq, s, "the start", j, it.src);
+        hipEvent_t ready = c->rk[it.src]->ready[s % kRing];
+        hipStream_t ps = me.peer_stream[it.src];
+        if (!ps) {                                                 // single-stream form: pulls one after the other
+            CHECK_HIP(hipStreamWaitEvent(st, ready, 0));
+            copy_f32(c, it.dst, j, it.from, it.src, it.count, st);
+            continue;
+        }
+        if (!forked) { CHECK_HIP(hipEventRecord(me.fork, st)); forked = true; }
+        CHECK_HIP(hipStreamWaitEvent(ps, me.fork, 0));             // the receive buffer is free (st has seen its last readers)
+        CHECK_HIP(hipStreamWaitEvent(ps, ready, 0));
+        copy_f32(c, it.dst, j, it.from, it.src, it.count, ps);
+        joined[it.src] = 1;
     }
-    for (int i = 0; i < P; i++) {
-        CHECK_HIP(hipSetDevice(c->devices[i]));
-        for (int j = 0; j < P; j++)
-            if (i != j) CHECK_HIP(hipStreamWaitEvent(as_stream(streams[i]), c->done[j], 0));
+    for (int i = 0; i < size_of(c); i++)
+        if (joined[i]) {
+            CHECK_HIP(hipEventRecord(me.peer_done[i], me.peer_stream[i]));
+            CHECK_HIP(hipStreamWaitEvent(st, me.peer_done[i], 0));
+        }
+    CHECK_HIP(hipEventRecord(me.done[s % kRing], st));
+    me.done_seq.store(s, std::memory_order_release);
+}
+
+void p2p_finish(mggcn_comm *c, int j, hipStream_t st, bool may_defer) {
+    if (may_defer && (c->flags & MGGCN_COMM_DEFER_RELEASE)) return;
+    p2p_release_rank(c, j, st);
+}
+
+// ---- what each rank pulls, per collective ---------------------------------------------------
+std::vector<pull_item> broadcast_items(const mggcn_comm *, int j, const float *send_root, float *const *recv, size_t count, int root) {
+    if (recv[j] == send_root) return {};
+    return {{root, recv[j], send_root, count}};
+}
+
+std::vector<pull_item> allgather_items(const mggcn_comm *c, int j, const float *const *send, float *const *recv, size_t count) {
+    std::vector<pull_item> v;
+    for (int i = 0; i < size_of(c); i++) {
+        float *dst = recv[j] + (size_t)i * count;
+        if (dst == send[i]) continue;
+        if (i == j && (c->flags & MGGCN_COMM_SKIP_SELF)) continue;
+        v.push_back({i, dst, send[i], count});
     }
+    return v;
+}
+
+std::vector<pull_item> alltoallv_items(const mggcn_comm *c, int k, const float *const *send, float *const *recv,
+                                       const size_t *counts, const std::vector<size_t> &sdis, const std::vector<size_t> &rdis) {
+    const int P = size_of(c);
+    std::vector<pull_item> v;
+    for (int j = 0; j < P; j++)
+        v.push_back({j, recv[k] + rdis[(size_t)k * P + j], send[j] + sdis[(size_t)j * P + k], counts[(size_t)j * P + k]});
+    return v;
+}
+
+void allreduce_scratch(mggcn_comm *c, int j, size_t count) {
+    rank_state &me = *c->rk[j];
+    const size_t need = (size_t)size_of(c) * count;
+    if (me.scratch_floats >= need) return;
+    CHECK_HIP(hipSetDevice(c->devices[j]));
+    CHECK_HIP(hipDeviceSynchronize());
+    if (me.scratch) CHECK_HIP(hipFree(me.scratch));
+    CHECK_HIP(hipMalloc(&me.scratch, need * sizeof(float)));
+    me.scratch_floats = need;
+}
+
+std::vector<pull_item> allreduce_items(mggcn_comm *c, int j, float *const *bufs, size_t count) {
+    std::vector<pull_item> v;
+    for (int i = 0; i < size_of(c); i++) v.push_back({i, c->rk[j]->scratch + (size_t)i * count, bufs[i], count});
+    return v;
+}
+
+// every rank holds all P contributions and nobody reads bufs[] any more: sum in rank order
+void allreduce_sum_local(mggcn_comm *c, int j, float *buf, size_t count, mggcn_stream_t stream) {
+    CHECK_HIP(hipSetDevice(c->devices[j]));
+    CHECK_HIP(hipMemcpyAsync(buf, c->rk[j]->scratch, count * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream)));
+    for (int i = 1; i < size_of(c); i++) mggcn_axpy_f32(stream, c->rk[j]->scratch + (size_t)i * count, buf, 1.0f, count);
 }
 
 }  // namespace
 
 MGGCN_API mggcn_comm *mggcn_comm_init_all(int P, const int *devices) {
-    if (P <= 0) {
-        std::fprintf(stderr, "MGGCN precondition failed: communicator size must be positive\n");
-        std::exit(EXIT_FAILURE);
-    }
+    require(P > 0, "communicator size must be positive");
     auto *c = new mggcn_comm;
     c->devices.resize(P);
     for (int i = 0; i < P; i++) c->devices[i] = devices ? devices[i] : i;
     const std::set<int> distinct(c->devices.begin(), c->devices.end());
     const char *tr = std::getenv("MGGCN_COMM_TRANSPORT");
     c->p2p = (int)distinct.size() != P || (tr && std::strcmp(tr, "p2p") == 0);
-    if (tr && std::strcmp(tr, "rccl") == 0 && (int)distinct.size() != P) {
-        std::fprintf(stderr, "MGGCN precondition failed: MGGCN_COMM_TRANSPORT=rccl needs one GPU per rank\n");
-        std::exit(EXIT_FAILURE);
-    }
+    require(!(tr && std::strcmp(tr, "rccl") == 0 && (int)distinct.size() != P), "MGGCN_COMM_TRANSPORT=rccl needs one GPU per rank");
     if (!c->p2p) {
         c->comms.resize(P);
         CHECK_RCCL(ncclCommInitAll(c->comms.data(), P, c->devices.data()));
@@ -124,14 +282,28 @@ MGGCN_API mggcn_comm *mggcn_comm_init_all(int P, const int *devices) {
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) CHECK_HIP(e);
             (void)hipGetLastError();
         }
-    c->ready.resize(P);
-    c->done.resize(P);
-    c->scratch.assign(P, nullptr);
-    c->scratch_floats.assign(P, 0);
-    for (int i = 0; i < P; i++) {
-        CHECK_HIP(hipSetDevice(c->devices[i]));
-        CHECK_HIP(hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming));
-        CHECK_HIP(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
+    // one pulling stream per (receiver, sender) pair so that a GPU's links work side by side; MGGCN_P2P_PEER_STREAMS=0:
+    // every rank pulls on the caller's stream, one copy after the other (the round-3 form)
+    const char *ps = std::getenv("MGGCN_P2P_PEER_STREAMS");
+    const bool peer_streams = !(ps && std::atoi(ps) == 0) && P > 2;
+    for (int j = 0; j < P; j++) {
+        c->rk.push_back(std::make_unique<rank_state>());
+        rank_state &r = *c->rk.back();
+        CHECK_HIP(hipSetDevice(c->devices[j]));
+        for (int k = 0; k < kRing; k++) {
+            CHECK_HIP(hipEventCreateWithFlags(&r.ready[k], hipEventDisableTiming));
+            CHECK_HIP(hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming));
+        }
+        CHECK_HIP(hipEventCreateWithFlags(&r.fork, hipEventDisableTiming));
+        r.peer_stream.assign(P, nullptr);
+        r.peer_done.assign(P, nullptr);
+        int least = 0, greatest = 0;
+        CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        for (int i = 0; i < P && peer_streams; i++) {
+            if (i == j) continue;
+            CHECK_HIP(hipStreamCreateWithPriority(&r.peer_stream[i], hipStreamNonBlocking, greatest));
+            CHECK_HIP(hipEventCreateWithFlags(&r.peer_done[i], hipEventDisableTiming));
+        }
     }
     return c;
 }
@@ -139,26 +311,58 @@ MGGCN_API mggcn_comm *mggcn_comm_init_all(int P, const int *devices) {
 MGGCN_API void mggcn_comm_destroy(mggcn_comm *comm) {
     if (!comm) return;
     for (auto &c : comm->comms) ncclCommDestroy(c);
-    for (size_t i = 0; i < comm->ready.size(); i++) {
-        (void)hipSetDevice(comm->devices[i]);
-        (void)hipEventDestroy(comm->ready[i]);
-        (void)hipEventDestroy(comm->done[i]);
-        if (comm->scratch[i]) (void)hipFree(comm->scratch[i]);
+    for (size_t j = 0; j < comm->rk.size(); j++) {
+        rank_state &r = *comm->rk[j];
+        (void)hipSetDevice(comm->devices[j]);
+        for (int k = 0; k < kRing; k++) { (void)hipEventDestroy(r.ready[k]); (void)hipEventDestroy(r.done[k]); }
+        (void)hipEventDestroy(r.fork);
+        for (auto &s : r.peer_stream) if (s) (void)hipStreamDestroy(s);
+        for (auto &e : r.peer_done) if (e) (void)hipEventDestroy(e);
+        if (r.scratch) (void)hipFree(r.scratch);
     }
     delete comm;
 }
 
-MGGCN_API int mggcn_comm_size(const mggcn_comm *comm) { return (int)comm->devices.size(); }
+MGGCN_API int mggcn_comm_size(const mggcn_comm *comm) { return size_of(comm); }
 
 MGGCN_API const char *mggcn_comm_transport(const mggcn_comm *comm) { return comm->p2p ? "p2p" : "rccl"; }
 
-MGGCN_API void mggcn_comm_broadcast_f32(mggcn_comm *comm, const float *send_root, float *const *recv,
-                                        size_t count, int root, const mggcn_stream_t *streams) {
-    const int P = (int)comm->devices.size();
+MGGCN_API void mggcn_comm_set_exchange_flags(mggcn_comm *comm, unsigned flags) { comm->flags = flags; }
+
+MGGCN_API void mggcn_comm_release(mggcn_comm *comm, const mggcn_stream_t *streams) {
+    if (!comm->p2p) return;
+    for (int j = 0; j < size_of(comm); j++) {
+        CHECK_HIP(hipSetDevice(comm->devices[j]));
+        p2p_release_rank(comm, j, as_stream(streams[j]));
+    }
+}
+
+MGGCN_API void mggcn_comm_release_rank(mggcn_comm *comm, int rank, mggcn_stream_t stream) {
+    if (!comm->p2p) return;
+    CHECK_HIP(hipSetDevice(comm->devices[rank]));
+    p2p_release_rank(comm, rank, as_stream(stream));
+}
+
+// ---- all ranks from the calling thread --------------------------------------------------------
+namespace {
+template <typename Items>
+void p2p_all_ranks(mggcn_comm *c, const mggcn_stream_t *streams, bool may_defer, Items &&items) {
+    const int P = size_of(c);
+    std::vector<std::uint64_t> s(P);
+    for (int j = 0; j < P; j++) s[j] = p2p_begin(c, j, as_stream(streams[j]));
+    for (int j = 0; j < P; j++) p2p_pull(c, j, s[j], as_stream(streams[j]), items(j));
+    for (int j = 0; j < P; j++) {
+        CHECK_HIP(hipSetDevice(c->devices[j]));
+        p2p_finish(c, j, as_stream(streams[j]), may_defer);
+    }
+}
+}  // namespace
+
+MGGCN_API void mggcn_comm_broadcast_f32(mggcn_comm *comm, const float *send_root, float *const *recv, size_t count,
+                                        int root, const mggcn_stream_t *streams) {
+    const int P = size_of(comm);
     if (comm->p2p) {
-        p2p_exchange(comm, streams, [&](int j) {
-            if (recv[j] != send_root) copy_f32(comm, recv[j], j, send_root, root, count, as_stream(streams[j]));
-        });
+        p2p_all_ranks(comm, streams, true, [&](int j) { return broadcast_items(comm, j, send_root, recv, count, root); });
         return;
     }
     CHECK_RCCL(ncclGroupStart());
@@ -169,15 +373,11 @@ MGGCN_API void mggcn_comm_broadcast_f32(mggcn_comm *comm, const float *send_root
     CHECK_RCCL(ncclGroupEnd());
 }
 
-MGGCN_API void mggcn_comm_allgather_f32(mggcn_comm *comm, const float *const *send, float *const *recv,
-                                        size_t count, const mggcn_stream_t *streams) {
-    const int P = (int)comm->devices.size();
+MGGCN_API void mggcn_comm_allgather_f32(mggcn_comm *comm, const float *const *send, float *const *recv, size_t count,
+                                        const mggcn_stream_t *streams) {
+    const int P = size_of(comm);
     if (comm->p2p) {
-        p2p_exchange(comm, streams, [&](int j) {
-            for (int i = 0; i < P; i++)
-                if (recv[j] + (size_t)i * count != send[i])
-                    copy_f32(comm, recv[j] + (size_t)i * count, j, send[i], i, count, as_stream(streams[j]));
-        });
+        p2p_all_ranks(comm, streams, true, [&](int j) { return allgather_items(comm, j, send, recv, count); });
         return;
     }
     CHECK_RCCL(ncclGroupStart());
@@ -192,56 +392,42 @@ MGGCN_API void mggcn_comm_alltoallv_displacements(int P, const size_t *counts, s
     mggcn_layout::alltoallv_displacements(P, counts, sdis, rdis);
 }
 
+namespace {
+void rccl_alltoallv_rank(mggcn_comm *comm, int j, const float *const *send, float *const *recv, const size_t *counts,
+                         const std::vector<size_t> &sdis, const std::vector<size_t> &rdis, mggcn_stream_t stream) {
+    const int P = size_of(comm);
+    CHECK_HIP(hipSetDevice(comm->devices[j]));
+    for (int k = 0; k < P; k++) {
+        const size_t out = counts[(size_t)j * P + k], in = counts[(size_t)k * P + j];
+        if (out) CHECK_RCCL(ncclSend(send[j] + sdis[(size_t)j * P + k], out, ncclFloat32, k, comm->comms[j], as_stream(stream)));
+        if (in) CHECK_RCCL(ncclRecv(recv[j] + rdis[(size_t)j * P + k], in, ncclFloat32, k, comm->comms[j], as_stream(stream)));
+    }
+}
+}  // namespace
+
 MGGCN_API void mggcn_comm_alltoallv_f32(mggcn_comm *comm, const float *const *send, float *const *recv,
                                         const size_t *counts, const mggcn_stream_t *streams) {
-    const int P = (int)comm->devices.size();
+    const int P = size_of(comm);
     std::vector<size_t> sdis((size_t)P * P, 0), rdis((size_t)P * P, 0);
     mggcn_comm_alltoallv_displacements(P, counts, sdis.data(), rdis.data());
     if (comm->p2p) {
-        p2p_exchange(comm, streams, [&](int k) {
-            for (int j = 0; j < P; j++)
-                copy_f32(comm, recv[k] + rdis[(size_t)k * P + j], k, send[j] + sdis[(size_t)j * P + k], j,
-                         counts[(size_t)j * P + k], as_stream(streams[k]));
-        });
+        p2p_all_ranks(comm, streams, true, [&](int k) { return alltoallv_items(comm, k, send, recv, counts, sdis, rdis); });
         return;
     }
     CHECK_RCCL(ncclGroupStart());
-    for (int j = 0; j < P; j++) {
-        CHECK_HIP(hipSetDevice(comm->devices[j]));
-        for (int k = 0; k < P; k++) {
-            const size_t out = counts[(size_t)j * P + k], in = counts[(size_t)k * P + j];
-            if (out) CHECK_RCCL(ncclSend(send[j] + sdis[(size_t)j * P + k], out, ncclFloat32, k, comm->comms[j], as_stream(streams[j])));
-            if (in) CHECK_RCCL(ncclRecv(recv[j] + rdis[(size_t)j * P + k], in, ncclFloat32, k, comm->comms[j], as_stream(streams[j])));
-        }
-    }
+    for (int j = 0; j < P; j++) rccl_alltoallv_rank(comm, j, send, recv, counts, sdis, rdis, streams[j]);
     CHECK_RCCL(ncclGroupEnd());
 }
 
 MGGCN_API void mggcn_comm_allreduce_sum_f32(mggcn_comm *comm, float *const *bufs, size_t count,
                                             const mggcn_stream_t *streams) {
-    const int P = (int)comm->devices.size();
+    const int P = size_of(comm);
     if (comm->p2p) {
         if (P == 1 || count == 0) return;
-        for (int j = 0; j < P; j++)
-            if (comm->scratch_floats[j] < (size_t)P * count) {
-                CHECK_HIP(hipSetDevice(comm->devices[j]));
-                CHECK_HIP(hipDeviceSynchronize());
-                if (comm->scratch[j]) CHECK_HIP(hipFree(comm->scratch[j]));
-                CHECK_HIP(hipMalloc(&comm->scratch[j], (size_t)P * count * sizeof(float)));
-                comm->scratch_floats[j] = (size_t)P * count;
-            }
-        p2p_exchange(comm, streams, [&](int j) {
-            for (int i = 0; i < P; i++)
-                copy_f32(comm, comm->scratch[j] + (size_t)i * count, j, bufs[i], i, count, as_stream(streams[j]));
-        });
-        // every rank holds all P contributions and nobody reads bufs[] any more: sum in rank order
-        for (int j = 0; j < P; j++) {
-            CHECK_HIP(hipSetDevice(comm->devices[j]));
-            CHECK_HIP(hipMemcpyAsync(bufs[j], comm->scratch[j], count * sizeof(float), hipMemcpyDeviceToDevice,
-                                     as_stream(streams[j])));
-            for (int i = 1; i < P; i++)
-                mggcn_axpy_f32(streams[j], comm->scratch[j] + (size_t)i * count, bufs[j], 1.0f, count);
-        }
+        for (int j = 0; j < P; j++) allreduce_scratch(comm, j, count);
+        // never deferred: bufs[] is overwritten with the sum right away
+        p2p_all_ranks(comm, streams, false, [&](int j) { return allreduce_items(comm, j, bufs, count); });
+        for (int j = 0; j < P; j++) allreduce_sum_local(comm, j, bufs[j], count, streams[j]);
         return;
     }
     CHECK_RCCL(ncclGroupStart());
@@ -250,4 +436,61 @@ MGGCN_API void mggcn_comm_allreduce_sum_f32(mggcn_comm *comm, float *const *bufs
         CHECK_RCCL(ncclAllReduce(bufs[j], bufs[j], count, ncclFloat32, ncclSum, comm->comms[j], as_stream(streams[j])));
     }
     CHECK_RCCL(ncclGroupEnd());
+}
+
+// ---- one rank's share, from that rank's enqueue thread ----------------------------------------
+namespace {
+void p2p_one_rank(mggcn_comm *c, int j, mggcn_stream_t stream, bool may_defer, const std::vector<pull_item> &items) {
+    const std::uint64_t s = p2p_begin(c, j, as_stream(stream));
+    p2p_pull(c, j, s, as_stream(stream), items);
+    p2p_finish(c, j, as_stream(stream), may_defer);
+}
+}  // namespace
+
+MGGCN_API void mggcn_comm_broadcast_rank_f32(mggcn_comm *comm, int rank, const float *send_root, float *const *recv,
+                                             size_t count, int root, mggcn_stream_t stream) {
+    if (comm->p2p) {
+        p2p_one_rank(comm, rank, stream, true, broadcast_items(comm, rank, send_root, recv, count, root));
+        return;
+    }
+    CHECK_HIP(hipSetDevice(comm->devices[rank]));
+    CHECK_RCCL(ncclBroadcast(send_root, recv[rank], count, ncclFloat32, root, comm->comms[rank], as_stream(stream)));
+}
+
+MGGCN_API void mggcn_comm_allgather_rank_f32(mggcn_comm *comm, int rank, const float *const *send, float *const *recv,
+                                             size_t count, mggcn_stream_t stream) {
+    if (comm->p2p) {
+        p2p_one_rank(comm, rank, stream, true, allgather_items(comm, rank, send, recv, count));
+        return;
+    }
+    CHECK_HIP(hipSetDevice(comm->devices[rank]));
+    CHECK_RCCL(ncclAllGather(send[rank], recv[rank], count, ncclFloat32, comm->comms[rank], as_stream(stream)));
+}
+
+MGGCN_API void mggcn_comm_alltoallv_rank_f32(mggcn_comm *comm, int rank, const float *const *send, float *const *recv,
+                                             const size_t *counts, mggcn_stream_t stream) {
+    const int P = size_of(comm);
+    std::vector<size_t> sdis((size_t)P * P, 0), rdis((size_t)P * P, 0);
+    mggcn_comm_alltoallv_displacements(P, counts, sdis.data(), rdis.data());
+    if (comm->p2p) {
+        p2p_one_rank(comm, rank, stream, true, alltoallv_items(comm, rank, send, recv, counts, sdis, rdis));
+        return;
+    }
+    CHECK_RCCL(ncclGroupStart());                     // this rank's sends and receives are one operation
+    rccl_alltoallv_rank(comm, rank, send, recv, counts, sdis, rdis, stream);
+    CHECK_RCCL(ncclGroupEnd());
+}
+
+MGGCN_API void mggcn_comm_allreduce_sum_rank_f32(mggcn_comm *comm, int rank, float *const *bufs, size_t count,
+                                                 mggcn_stream_t stream) {
+    const int P = size_of(comm);
+    if (comm->p2p) {
+        if (P == 1 || count == 0) return;
+        allreduce_scratch(comm, rank, count);
+        p2p_one_rank(comm, rank, stream, false, allreduce_items(comm, rank, bufs, count));
+        allreduce_sum_local(comm, rank, bufs[rank], count, stream);
+        return;
+    }
+    CHECK_HIP(hipSetDevice(comm->devices[rank]));
+    CHECK_RCCL(ncclAllReduce(bufs[rank], bufs[rank], count, ncclFloat32, ncclSum, comm->comms[rank], as_stream(stream)));
 }

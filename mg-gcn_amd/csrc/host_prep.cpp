@@ -30,8 +30,11 @@ unsigned host_threads(size_t work, size_t per_thread_bytes = 0) {
     if (const char *s = std::getenv("MGGCN_HOST_THREADS")) hw = (unsigned)std::strtoul(s, nullptr, 10);
     if (hw < 1) hw = 1;
     if (hw > 64) hw = 64;
-    // below ~1M non-zeros the thread start-up costs more than it saves
-    const unsigned by_work = (unsigned)std::max<size_t>(1, work >> 20);
+    // below ~1M non-zeros per thread the thread start-up costs more than it saves (MGGCN_HOST_THREADS_MIN_NNZ: the
+    // sanitizer tests thread small matrices)
+    size_t per_thread = (size_t)1 << 20;
+    if (const char *s = std::getenv("MGGCN_HOST_THREADS_MIN_NNZ")) per_thread = std::max<size_t>(1, std::strtoull(s, nullptr, 10));
+    const unsigned by_work = (unsigned)std::min<size_t>(64, std::max<size_t>(1, work / per_thread));
     unsigned T = std::min(hw, by_work);
     if (per_thread_bytes) T = std::min<unsigned>(T, (unsigned)std::max<size_t>(1, (2ull << 30) / per_thread_bytes));
     return T;

@@ -35,25 +35,16 @@
 #include <chrono>
 #include <cstdio>
 
+#include "plan_host.h"
 #include "spmm_internal.h"
 
+// work items / split rows of the row-split form and the host passes of the plan builder: plan_host.h (free of HIP)
+using mggcn_plan::env_u32;
+using mggcn_plan::kNoSlot;
+using mggcn_plan::SplitRow;
+using mggcn_plan::SpmmItem;
+
 namespace {
-
-constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
-
-struct SpmmItem {
-    uint32_t row;   // output row
-    uint32_t beg;   // first non-zero (absolute offset into indices/values)
-    uint32_t end;   // one past the last
-    uint32_t slot;  // kNoSlot: write C directly; else: partial-sum slot
-};
-
-struct SplitRow {
-    uint32_t row;
-    uint32_t first_slot;
-    uint32_t n_slots;
-    uint32_t pad;
-};
 
 __device__ __forceinline__ float lrelu(float x, float slope) {
     const float y = slope * x;
@@ -247,38 +238,6 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(
     }
 }
 
-uint32_t env_u32(const char *name, uint32_t dflt) {
-    const char *s = std::getenv(name);
-    if (!s || !*s) return dflt;
-    return (uint32_t)std::strtoul(s, nullptr, 10);
-}
-
-}  // namespace
-
-namespace {
-// host passes of the plan builder over the rows of A, cut into ranges of about equal non-zeros, one std::thread each
-// (matrices below 2^22 non-zeros: the calling thread alone).  fn(thread, row_begin, row_end).
-template <typename F>
-void plan_rows_parallel(uint32_t n_rows, const uint32_t *indptr, F &&fn, unsigned *threads_out = nullptr) {
-    const uint64_t nnz = n_rows ? (uint64_t)indptr[n_rows] - indptr[0] : 0;
-    unsigned T = 1;
-    if (nnz > (1u << 22)) {
-        T = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-        if (const char *s = std::getenv("MGGCN_HOST_THREADS")) T = std::max(1u, std::min(64u, (unsigned)std::strtoul(s, nullptr, 10)));
-    }
-    if (threads_out) { *threads_out = T; return; }
-    std::vector<uint32_t> cut(T + 1, n_rows);
-    cut[0] = 0;
-    for (unsigned t = 1; t < T; t++) {
-        const uint64_t target = indptr[0] + nnz * t / T;
-        cut[t] = (uint32_t)(std::lower_bound(indptr, indptr + n_rows, (uint32_t)target) - indptr);
-        if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
-    }
-    if (T == 1) { fn(0u, 0u, n_rows); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; t++) th.emplace_back(fn, t, cut[t], cut[t + 1]);
-    for (auto &x : th) x.join();
-}
 }  // namespace
 
 struct mggcn_spmm_plan {
@@ -327,33 +286,14 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
     if (!narrow) d_hint = 0;
     MGGCN_REQUIRE(max_d > 0, "max_d must be positive");
     const auto t_build0 = std::chrono::steady_clock::now();
+    // one range check for every pass below (they index per-column tables with what they read)
+    MGGCN_REQUIRE(!host_indices || mggcn_plan::columns_in_range(n_rows, n_cols, host_indptr, host_indices), "column index out of range");
     // slice length for heavy rows; rows up to 1.5x the slice stay whole
     const uint32_t split = std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_SPLIT", 512u));
-
-    std::vector<SpmmItem> items;
-    std::vector<SplitRow> split_rows;
-    items.reserve((size_t)n_rows + 1024);
-    uint32_t n_slots = 0;
-    for (uint32_t r = 0; r < n_rows; r++) {
-        const uint32_t b = host_indptr[r], e = host_indptr[r + 1];
-        MGGCN_REQUIRE(e >= b, "indptr must be non-decreasing");
-        const uint32_t len = e - b;
-        if (len <= split + split / 2) {
-            items.push_back({r, b, e, kNoSlot});
-        } else {
-            const uint32_t parts = (len + split - 1) / split;
-            split_rows.push_back({r, n_slots, parts, 0});
-            for (uint32_t k = 0; k < parts; k++) {
-                const uint32_t kb = b + (uint32_t)((uint64_t)len * k / parts);
-                const uint32_t ke = b + (uint32_t)((uint64_t)len * (k + 1) / parts);
-                items.push_back({r, kb, ke, n_slots++});
-            }
-        }
-    }
-    // longest first (LPT); ties keep row order so neighbouring waves touch neighbouring C rows
-    std::stable_sort(items.begin(), items.end(), [](const SpmmItem &a, const SpmmItem &b) {
-        return (a.end - a.beg) > (b.end - b.beg);
-    });
+    const mggcn_plan::RowSplitHost rs = mggcn_plan::rowsplit_build(n_rows, host_indptr, split);
+    const auto &items = rs.items;
+    const auto &split_rows = rs.split_rows;
+    const uint32_t n_slots = rs.n_slots;
 
     auto *plan = new mggcn_spmm_plan;
     plan->n_rows = n_rows; plan->n_cols = n_cols; plan->max_d = max_d;
@@ -390,43 +330,12 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         // panels and 64 MiB slices (2.69 ms; 2.74 with 4096 / 32); the backward matrix (power-law rows,
         // uniformly popular columns) needs the tighter window: 2.86 ms with 4096 / 32 against 3.19
         // (profiles/experiments/sweep_vs_rowsplit.py, EXP_MATRIX=A).  Measure: share of the non-zeros
-        // that sit in the 1 % most popular columns.
-        bool hot_columns = true;
-        if (n_cols >= 100 && host_indices) {
-            const uint64_t nz0 = host_indptr[0], nz1 = host_indptr[n_rows];
-            // ... and, in the same pass, how much of the matrix sits near its diagonal: a vertex order with locality
-            // (an unpermuted community graph) -- see the column permutation below
-            const uint32_t gr = std::max<uint32_t>(1u, (n_rows + 31) / 32), gc = std::max<uint32_t>(1u, (n_cols + 31) / 32);
-            unsigned T = 1;
-            plan_rows_parallel(n_rows, host_indptr, [](unsigned, uint32_t, uint32_t) {}, &T);
-            std::vector<std::vector<uint32_t>> ccs(T, std::vector<uint32_t>(n_cols, 0u));
-            std::vector<uint64_t> nears(T, 0);
-            plan_rows_parallel(n_rows, host_indptr, [&](unsigned t, uint32_t r0, uint32_t r1) {
-                uint32_t *cnt = ccs[t].data();
-                uint64_t near_t = 0;
-                for (uint32_t r = r0; r < r1; r++) {
-                    const uint32_t g = r / gr;
-                    for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) {
-                        const uint32_t c = host_indices[e];
-                        if (c < n_cols) { cnt[c]++; near_t += (c / gc == g); }
-                    }
-                }
-                nears[t] = near_t;
-            });
-            std::vector<uint32_t> &cc = ccs[0];
-            uint64_t near = nears[0];
-            for (unsigned t = 1; t < T; t++) {
-                near += nears[t];
-                for (uint32_t c = 0; c < n_cols; c++) cc[c] += ccs[t][c];
-            }
-            plan->locality = nz1 > nz0 ? (double)near / (double)(nz1 - nz0) : 0.0;
-            const size_t top = std::max<size_t>(1, n_cols / 100);
-            std::nth_element(cc.begin(), cc.begin() + top, cc.end(), std::greater<uint32_t>());
-            uint64_t hot = 0;
-            for (size_t k = 0; k < top; k++) hot += cc[k];
-            hot_columns = (double)hot >= 0.05 * (double)(nz1 - nz0);
-            plan->hot_share = nz1 > nz0 ? (double)hot / (double)(nz1 - nz0) : 0.0;
-        }
+        // that sit in the 1 % most popular columns -- and, in the same pass, how much of the matrix sits near its
+        // diagonal: a vertex order with locality (an unpermuted community graph), see the column permutation below.
+        const mggcn_plan::ColumnStats cs = mggcn_plan::column_stats(n_rows, n_cols, host_indptr, host_indices);
+        bool hot_columns = cs.hot_columns;
+        plan->locality = cs.locality;
+        plan->hot_share = cs.hot_share;
         if (const char *hc = std::getenv("MGGCN_SPMM_HOT_COLUMNS")) hot_columns = std::atoi(hc) != 0;
         const uint64_t slice_rows = std::max<uint64_t>(
             64, env_u32("MGGCN_SPMM_SLICE_ROWS", (uint32_t)(((uint64_t)env_u32("MGGCN_SPMM_SLICE_MIB", 64u) << 20) / hint_bytes)));   // tests set ROWS
@@ -438,7 +347,7 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         // row-split 8.2 ms, sweep 15-38 ms (profiles/experiments/products_like.py).  Gate: mean
         // run length >= 2, and never more slices than leave ~64 non-zeros per (row, slice).
         const double avg_deg = n_rows ? (double)total_nnz / n_rows : 0.0;
-        const double panel_rows = sweep_panel_rows(d_hint, hot_columns);
+        const double panel_rows = mggcn_plan::sweep_panel_rows(d_hint, hot_columns);
         const double mean_run = n_cols ? avg_deg * std::min<double>(panel_rows, n_cols) / n_cols : 0.0;
         if (!std::getenv("MGGCN_SPMM_SLICE_ROWS")) S = std::max<uint32_t>(1u, std::min<uint32_t>(S, (uint32_t)(avg_deg / 64.0)));
         plan->hot_columns = hot_columns ? 1 : 0;
@@ -454,41 +363,14 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
         // permuted graph has 3 %, the same graph numbered by decreasing degree 11 %, 64 contiguous communities 85 %), the plan relabels the COLUMNS by a fixed pseudo-random permutation pi: the entry streams
         // are built on pi(column), and every call first copies B into the plan's scratch in permuted row order (one
         // streaming pass; the narrow form folds it into its re-pitch pass).  MGGCN_SPMM_PERMUTE_COLUMNS = 0 / 1 overrides.
-        std::vector<uint32_t> permuted_indices;
+        std::vector<uint32_t> permuted_indices, src_row;
         const uint32_t permute_knob = env_u32("MGGCN_SPMM_PERMUTE_COLUMNS", 2u);
-        if (worth_it && (permute_knob == 1u || (permute_knob == 2u && plan->locality >= 0.08)) && n_cols > 1) {
-            std::vector<uint32_t> pi(n_cols), src_row(n_cols);
-            for (uint32_t c = 0; c < n_cols; c++) pi[c] = c;
-            uint64_t x = 0x9E3779B97F4A7C15ull;                    // fixed-seed Fisher-Yates (splitmix64)
-            for (uint32_t c = n_cols - 1; c > 0; c--) {
-                x += 0x9E3779B97F4A7C15ull;
-                uint64_t z = x;
-                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-                z ^= z >> 31;
-                std::swap(pi[c], pi[(uint32_t)(z % (c + 1))]);
-            }
-            for (uint32_t c = 0; c < n_cols; c++) src_row[pi[c]] = c;
-            const uint64_t nz1 = host_indptr[n_rows];
-            permuted_indices.resize(nz1);                           // indexed like host_indices (the offset host_indptr[0] kept)
-            {
-                const uint32_t *src = host_indices;
-                plan_rows_parallel(n_rows, host_indptr, [&](unsigned, uint32_t r0, uint32_t r1) {
-                    for (uint64_t e = host_indptr[r0]; e < host_indptr[r1]; e++) {
-                        MGGCN_REQUIRE(src[e] < n_cols, "column index out of range");
-                        permuted_indices[e] = pi[src[e]];
-                    }
-                });
-            }
+        const bool permute = worth_it && (permute_knob == 1u || (permute_knob == 2u && plan->locality >= 0.08)) && n_cols > 1;
+        if (permute) {
+            std::vector<uint32_t> pi;
+            mggcn_plan::column_permutation(n_cols, pi, src_row);
+            mggcn_plan::permute_indices(n_rows, host_indptr, host_indices, pi, permuted_indices);   // indexed like host_indices
             host_indices = permuted_indices.data();
-            MGGCN_CHECK_HIP(hipMalloc(&plan->d_src_row, (size_t)n_cols * sizeof(uint32_t)));
-            MGGCN_CHECK_HIP(hipMemcpy(plan->d_src_row, src_row.data(), (size_t)n_cols * sizeof(uint32_t), hipMemcpyHostToDevice));
-            plan->bytes += (size_t)n_cols * sizeof(uint32_t);
-            {   // scratch for the permuted copy at any width <= max_d (a narrow plan also serves wide calls)
-                const size_t bb = (size_t)n_cols * ((max_d + 3) / 4 * 4) * sizeof(float);
-                MGGCN_CHECK_HIP(hipMalloc(&plan->d_bperm, bb));
-                plan->bytes += bb;
-            }
         }
         if (!worth_it) {
             // nothing
@@ -496,44 +378,32 @@ MGGCN_API mggcn_spmm_plan *mggcn_spmm_plan_create_for(uint32_t n_rows, uint32_t 
             if (SweepPlan *sp = sweep_plan_build(n_rows, n_cols, host_indptr, host_indices, host_values, max_d, true, d_hint, hot_columns))
                 plan->sweeps.push_back(sp);
         } else {
-            // bucket the non-zeros by column slice: two passes over A whatever the slice count
+            // bucket the non-zeros by column slice
             const uint32_t width = (n_cols + S - 1) / S;
-            std::vector<std::vector<uint32_t>> ips(S, std::vector<uint32_t>((size_t)n_rows + 1, 0u));
-            plan_rows_parallel(n_rows, host_indptr, [&](unsigned, uint32_t r0, uint32_t r1) {       // per-row counts: no sharing
-                for (uint32_t r = r0; r < r1; r++)
-                    for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) ips[host_indices[e] / width][r + 1]++;
-            });
-            std::vector<std::vector<uint32_t>> ixs(S);
-            std::vector<std::vector<float>> vvs(S);
-            for (uint32_t k = 0; k < S; k++) {
-                for (uint32_t r = 0; r < n_rows; r++) ips[k][r + 1] += ips[k][r];
-                ixs[k].resize(ips[k][n_rows]);
-                vvs[k].resize(ips[k][n_rows]);
-            }
-            plan_rows_parallel(n_rows, host_indptr, [&](unsigned, uint32_t r0, uint32_t r1) {       // every row knows its offsets
-                std::vector<uint32_t> pos(S);
-                for (uint32_t r = r0; r < r1; r++) {
-                    for (uint32_t k = 0; k < S; k++) pos[k] = ips[k][r];
-                    for (uint32_t e = host_indptr[r]; e < host_indptr[r + 1]; e++) {
-                        const uint32_t k = host_indices[e] / width;
-                        ixs[k][pos[k]] = host_indices[e];
-                        vvs[k][pos[k]] = host_values[e];
-                        pos[k]++;
-                    }
-                }
-            });
+            mggcn_plan::SliceBuckets sl = mggcn_plan::slice_buckets(n_rows, S, width, host_indptr, host_indices, host_values);
             bool ok = true;
             for (uint32_t k = 0; k < S && ok; k++) {
-                if (ixs[k].empty()) continue;            // e.g. a rank's own column range in its "remote" matrix
-                SweepPlan *sp = sweep_plan_build(n_rows, n_cols, ips[k].data(), ixs[k].data(), vvs[k].data(), max_d, true, d_hint, hot_columns);
+                if (sl.ixs[k].empty()) continue;            // e.g. a rank's own column range in its "remote" matrix
+                SweepPlan *sp = sweep_plan_build(n_rows, n_cols, sl.ips[k].data(), sl.ixs[k].data(), sl.vvs[k].data(), max_d, true, d_hint, hot_columns);
                 if (sp) plan->sweeps.push_back(sp); else ok = false;
-                std::vector<uint32_t>().swap(ixs[k]);        // release as we go
-                std::vector<float>().swap(vvs[k]);
+                std::vector<uint32_t>().swap(sl.ixs[k]);        // release as we go
+                std::vector<float>().swap(sl.vvs[k]);
             }
             if (!ok) {                                   // all or nothing: the slices must cover A
                 for (auto *sp : plan->sweeps) sweep_plan_destroy(sp);
                 plan->sweeps.clear();
             }
+        }
+        // the permutation's device side only when the sweep form it serves exists (a plan that fell back to the row-split
+        // kernels multiplies by the caller's B as it is)
+        if (permute && !plan->sweeps.empty()) {
+            MGGCN_CHECK_HIP(hipMalloc(&plan->d_src_row, (size_t)n_cols * sizeof(uint32_t)));
+            MGGCN_CHECK_HIP(hipMemcpy(plan->d_src_row, src_row.data(), (size_t)n_cols * sizeof(uint32_t), hipMemcpyHostToDevice));
+            plan->bytes += (size_t)n_cols * sizeof(uint32_t);
+            // scratch for the permuted copy at any width <= max_d (a narrow plan also serves wide calls)
+            const size_t bb = (size_t)n_cols * ((max_d + 3) / 4 * 4) * sizeof(float);
+            MGGCN_CHECK_HIP(hipMalloc(&plan->d_bperm, bb));
+            plan->bytes += bb;
         }
         if (narrow && !plan->sweeps.empty()) {
             plan->bpad_dp = (d_hint + 15) / 16 * 16;       // 64-byte pitch: see sweep_wants_repack
@@ -589,6 +459,8 @@ MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {
     delete plan;
 }
 
+MGGCN_API void mggcn_spmm_plan_concurrent_builders(uint32_t n) { mggcn_plan::set_concurrent_builders(n); }
+
 MGGCN_API uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan) { return plan->n_items; }
 MGGCN_API uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan) { return plan->n_split_rows; }
 MGGCN_API size_t mggcn_spmm_plan_bytes(const mggcn_spmm_plan *plan) {
@@ -609,6 +481,7 @@ MGGCN_API uint32_t mggcn_spmm_plan_num_launches(const mggcn_spmm_plan *plan, uin
     if (!plan) return 1;
     if (plan->sweeps.empty()) return 1 + (plan->n_split_rows ? 1 : 0);
     uint32_t n = (plan->d_bpad && (d + 15) / 16 * 16 <= plan->bpad_dp && d % 16 != 0) ? 1u : 0u;   // re-pitch pass
+    if (plan->d_src_row && !n) n = 1;                    // the permuted copy of B (the narrow form folds it into the re-pitch)
     for (auto *sp : plan->sweeps) n += sweep_plan_launches(sp, d);
     return n;
 }

@@ -12,9 +12,8 @@ struct SweepPlan;   // opaque to spmm.hip
 SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
                             const uint32_t *indices, const float *values, uint32_t max_d, bool force = false,
                             uint32_t d_hint = 0, bool hot_columns = true);
-// d_hint in 1..64 builds the narrow ("quad") form: runs padded to four entries, wider panels
-uint32_t sweep_panel_rows(uint32_t d_hint, bool hot_columns = true);
-uint32_t sweep_lanes_per_entry(uint32_t d_hint);   // 4 / 8 / 12 / 16 float4 lanes per gathered row
+// d_hint in 1..64 builds the narrow ("quad") form: runs padded to four entries, wider panels (plan_host.h:
+// sweep_panel_rows, sweep_lanes_per_entry)
 // narrow form only: true when B has to be re-pitched to 16-byte rows before sweep_launch
 bool sweep_wants_repack(const SweepPlan *p, uint32_t d, size_t ldb, const void *B);
 // copy of B at pitch dp (multiple of 4 floats); src_row != nullptr: row r of the copy = row src_row[r] of B

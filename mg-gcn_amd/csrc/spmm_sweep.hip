@@ -42,7 +42,12 @@
 #include <type_traits>
 #include <vector>
 
+#include "plan_host.h"
 #include "spmm_internal.h"
+
+// packed-entry constants, task / split-row records and the host passes of the plan builder: plan_host.h (free of HIP, so
+// that the sanitizers can run it on the CPU)
+using namespace mggcn_plan;
 
 // (hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b64/_b128 lower to a single dword load
 // splatted over the result -- checked in the IR -- so the LLVM intrinsics are bound directly.)
@@ -63,17 +68,6 @@ __device__ f32x4_t mggcn_buffer_load_v4f32(__amdgpu_buffer_rsrc_t rsrc, int voff
 
 namespace {
 
-constexpr int kRW = 16;                 // output rows per wave (5 bits available)
-constexpr uint32_t kColBits = 27;       // columns < 134 M (papers100M: 111 M)
-constexpr uint32_t kColMask = (1u << kColBits) - 1;
-constexpr uint32_t kSlotFlag = 0x80000000u;
-constexpr uint32_t kRunFlag = 0x80000000u;     // entry bit 31: first entry of a (panel,row) run; bits 30..27: row
-constexpr int kWavesPerBlock = 4;
-// internal launch flags (never part of the ABI's flags): bit 8 = rotate the wave priority, bits 12..15 = log2 of the
-// rotation period in entries
-constexpr uint32_t kFlagPrioRotate = 0x100u;
-constexpr uint32_t kPrioShiftPos = 12;
-
 // Priority rotation.  The four waves that share a SIMD are served oldest first: measured per hardware wave slot
 // (= blockIdx / 256: blocks are dealt one per CU per "layer"; profiles/experiments/wave_spread.py) equal tasks took
 // 305 / 308 / 317 / 330 us -- the youngest wave 8 % slower all launch long, so the waves spread over +-6 % of the
@@ -89,16 +83,6 @@ __device__ __forceinline__ void rotate_priority(uint32_t slot, uint32_t phase) {
         default: __builtin_amdgcn_s_setprio(3); break;
     }
 }
-
-struct SweepTask {
-    uint32_t beg, end;   // entry range
-    uint32_t n_rows;     // rows in use (<= kRW)
-    uint32_t pad;
-};
-
-struct SweepSplitRow {
-    uint32_t row, first_slot, n_slots, pad;
-};
 
 __device__ __forceinline__ float lrelu(float x, float slope) {
     const float y = slope * x;
@@ -380,7 +364,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, b_bytes, 0x00020000);
     const uint32_t sub = lane & 31;
     const uint32_t hmask = (lane & 32) ? 0xFFFFFFFFu : 0u;     // upper half-wave takes the pair's 2nd entry
-    const uint32_t prio_slot = blockIdx.x / kNumCU;            // blocks are dealt one per CU per "layer": layer = hardware wave slot
+    const uint32_t prio_slot = blockIdx.x / ((flags >> kNumCuPos) & kNumCuMask);   // blocks are dealt one per CU per "layer": layer = hardware wave slot
     const uint32_t prio_shift = (flags >> kPrioShiftPos) & 15u, prio_mask = (1u << prio_shift) - 1u;
 
     // one task per wave per launch by default (wave_stride >= n_launch); MGGCN_SPMM_TASKS_PER_WAVE > 1 lets a wave walk
@@ -616,7 +600,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr
         const uint32_t n_chunks = (n_ent + CH - 1) / CH;  // the plan leaves a chunk of slack after the last task
         ring[wib][0][lane] = stream[0];
         uint4 pre = stream[n_chunks > 1 ? CH / 2 : 0];
-        const uint32_t prio_slot = blockIdx.x / kNumCU;
+        const uint32_t prio_slot = blockIdx.x / ((flags >> kNumCuPos) & kNumCuMask);
         const uint32_t prio_shift = (flags >> kPrioShiftPos) & 15u;          // in chunks of CH (~128) entries here
         f32x4_t b[4];
 #pragma unroll
@@ -730,40 +714,9 @@ __global__ __launch_bounds__(256) void sweep_combine_kernel(
     }
 }
 
-uint32_t env_u32(const char *name, uint32_t dflt) {
-    const char *s = std::getenv(name);
-    if (!s || !*s) return dflt;
-    return (uint32_t)std::strtoul(s, nullptr, 10);
-}
-
-struct VRow {
-    uint32_t row, beg, end, dst, step;      // entries beg, beg + step, beg + 2 step, ... < end
-    uint32_t len() const { return (end - beg + step - 1) / step; }
-};
-
 }  // namespace
 
-uint32_t sweep_lanes_per_entry(uint32_t d_hint) {
-    const uint32_t need = (d_hint + 3) / 4;          // float4 lanes that cover a row
-    return need <= 4 ? 4u : need <= 8 ? 8u : need <= 12 ? 12u : 16u;
-}
-
-// hot_columns: a few columns carry much of the matrix (see mggcn_spmm_plan_create_for)
-uint32_t sweep_panel_rows(uint32_t d_hint, bool hot_columns) {
-    if (d_hint >= 1 && d_hint <= 64) {
-        // 1.5 MiB of B per panel at the 64-byte-multiple pitch: 8192 rows at d = 41 (best of 8192 /
-        // 16384 / 32768 on both Reddit matrices), 24576 at d = 16 (16384 beat 8192 there)
-        const uint32_t pitch = (d_hint + 15) / 16 * 64;
-        const uint32_t rows = std::max(1024u, (3u << 19) / pitch / 1024u * 1024u);
-        return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS_NARROW", rows));
-    }
-    // Round 1 (no priority rotation): 6144 rows for the forward matrix (hot columns), 4096 for the backward one.  With the
-    // waves of a SIMD equalised (rotate_priority) 4096-row panels (2 MiB) win on both: forward 2.45 -> 2.42 ms, and the
-    // backward matrix no longer needs 32-MiB slices (profiles/experiments/retune_after_rotation_r02.log).
-    (void)hot_columns;
-    return std::max<uint32_t>(64u, env_u32("MGGCN_SPMM_PANEL_ROWS", 4096u));
-}
-
+// the host side of a sweep plan (mggcn_plan::SweepHost: tasks, entry stream, row tables, knobs) + its device image
 struct SweepPlan {
     uint32_t n_rows = 0, n_cols = 0, max_d = 0;
     uint32_t n_tasks = 0, round_tasks = 0, n_split_rows = 0, n_slots = 0;
@@ -777,323 +730,53 @@ struct SweepPlan {
     unsigned long long *d_stamps = nullptr;   // diagnostics: 3 words per task (MGGCN_SPMM_STAMPS=1)
     size_t bytes = 0;
     // tuning knobs, read from the environment ONCE when the plan is built (never on the launch path)
-    uint32_t panel_rows = 0;
+    uint32_t panel_rows = 0, num_cu = 0;
     uint64_t n_entries = 0;        // padded entry stream length
-    uint32_t prio_bits_wide = 0, prio_bits_narrow = 0;   // kFlagPrioRotate | shift << kPrioShiftPos, or 0
+    uint32_t prio_bits_wide = 0, prio_bits_narrow = 0;   // kFlagPrioRotate | shift << kPrioShiftPos | CUs << kNumCuPos
     uint32_t tasks_per_wave = 1;
     bool allow_quad = true, allow_vec4 = true, fast_pairs = true;
 };
 
+// compute units of the current device (a launch round is sized to the resident set; a partitioned device has fewer)
+static uint32_t device_compute_units() {
+    int dev = 0, cus = 0;
+    MGGCN_CHECK_HIP(hipGetDevice(&dev));
+    MGGCN_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    return (uint32_t)std::max(cus, 1);
+}
+
 SweepPlan *sweep_plan_build(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr,
                             const uint32_t *indices, const float *values, uint32_t max_d, bool force,
                             uint32_t d_hint, bool hot_columns) {
-    if (!n_rows || !indices || !values) return nullptr;
-    // narrow form (quad kernel): runs padded to 4 entries, tasks to 16, wider panels (the L2
-    // window is counted in bytes: a 176-byte row lets three times as many rows stay resident)
-    const bool narrow = d_hint >= 1 && d_hint <= 64 && n_cols <= (1u << 24);
-    // lanes per gathered row / entries per gather instruction: the fewest lanes that cover the row
-    // give the most rows per instruction, but every run is padded to G entries -- on a matrix with
-    // many short runs (power-law rows) a smaller G wins.  Decided after the counting pass below.
-    uint32_t lpe = !narrow ? 0u : sweep_lanes_per_entry(d_hint);
-    uint32_t G = narrow ? 64u / lpe : 2u;
-    if (n_cols > kColMask) return nullptr;                          // column does not fit the packed entry
-    static_assert(kRW == 16, "4 row bits in the packed entry");
-    const uint64_t nnz = (uint64_t)indptr[n_rows] - indptr[0];
-    if (!force && nnz < env_u32("MGGCN_SPMM_SWEEP_MIN_NNZ", 1u << 20)) return nullptr;   // small graphs: row-split is fine
-    const uint32_t panel_rows = sweep_panel_rows(d_hint, hot_columns);
-
-    // resident waves per launch ("round").  Registers would admit 6 blocks of 4 waves per CU
-    // (56 VGPRs; ~106 SGPRs -> floor(800 / (ceil(sgpr/16)*16 + 16)) = 6, MI355X_MICROARCH.md
-    // residency rule), but FEWER waves keep the sweep tighter: the spread of the waves over the
-    // column space is what decides the L2 hit rate.  Measured on the Reddit shape, d = 128
-    // (profiles/experiments/sweep_vs_rowsplit.py): 2 blocks/CU 3.96 ms, 3 -> 3.34 ms, 4 -> 4.0,
-    // 5 -> 4.0, 6 -> 4.4 (row-split kernel: 5.96 ms).  With the float4 pair kernel and 32 MiB
-    // column slices (spmm.hip) the optimum moved to 4 blocks/CU, 8192-row panels: 2.83 ms; with
-    // the accumulators in reserved registers and the six-instruction fold, 6144-row panels and
-    // 64 MiB slices: 2.69 ms (3 blocks/CU 3.11, 5 -> 3.56; the float4 kernels hold 128 VGPRs, so
-    // four blocks of four waves is also what fits).
-    const uint32_t blocks_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u), 8u));
-    const uint32_t round_tasks = kNumCU * blocks_per_cu * kWavesPerBlock;
-
-    // (MGGCN_SPMM_SWEEP_ROWS_PER_TASK caps it for experiments: 8 rows per wave -- twice the launches,
-    //  same slices -- ran 2.88 ms against 2.69 at 16, 4 rows 3.00: profiles/experiments/sweep_rows_per_task_r01.log)
-    // 1. virtual rows: slices of heavy rows get partial-sum slots
-    // rows per task: 16 when there are enough rows to fill a round, fewer for small row blocks
-    // (a rank's share at P = 8 has 29 k rows: 16 rows per wave would leave 7 waves per CU)
-    const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t)kRW, std::max(1u, env_u32("MGGCN_SPMM_SWEEP_ROWS_PER_TASK", (uint32_t)kRW))), (n_rows + round_tasks - 1) / round_tasks));
-    const uint32_t t_est = (n_rows + cap_rows - 1) / cap_rows;
-    const uint32_t target = (uint32_t)std::max<uint64_t>(1, nnz / t_est);
-    const uint32_t split = std::max<uint32_t>(256u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_SPLIT", target / 2), 1u << 20));
-    std::vector<VRow> vrows;
-    vrows.reserve((size_t)n_rows + 4096);
-    std::vector<SweepSplitRow> split_rows;
-    uint32_t n_slots = 0;
-    uint32_t T = 0;
-    std::vector<std::vector<uint32_t>> bins;
-    // EXPERIMENT (MGGCN_SPMM_XCD_COLUMNS=1, wide form only): a column partition across the 8 XCDs.
-    // Every row is cut into 8 column slices (entries regrouped by slice), every slice of every row gets a partial-sum
-    // slot, tasks hold rows of ONE slice, and the task table is laid out so that the workgroups the dispatcher deals to
-    // XCD x (block index mod 8 == x) only ever touch slice x of B: each XCD's L2 pulls 1/8 of B per round of resident
-    // tasks instead of all of it.  The price: 8 partial rows per output row (written, then summed by
-    // sweep_combine_kernel) and 8x as many one-wave tasks.  Kernels unchanged.  profiles/experiments/xcd_columns_r03.log.
-    const uint32_t XS = (!narrow && env_u32("MGGCN_SPMM_XCD_COLUMNS", 0u) && n_cols >= 8u * panel_rows) ? 8u : 1u;
-    const uint32_t xs_width = (n_cols + XS - 1) / XS;
-    std::vector<uint32_t> idx2;
-    std::vector<float> val2;
-    const uint32_t *ix = indices;
-    const float *vv = values;
-    auto lpt = [&](const std::vector<uint32_t> &members, uint32_t n_bins, auto &&bin_of) {
-        // equal-work bins of <= cap_rows virtual rows: longest first into the lightest bin
-        std::vector<uint32_t> order(members);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return vrows[a].len() > vrows[b].len(); });
-        std::vector<uint64_t> load(n_bins, 0);
-        using HeapItem = std::pair<uint64_t, uint32_t>;        // (load, bin): smallest load first, then lowest id
-        std::priority_queue<HeapItem, std::vector<HeapItem>, std::greater<HeapItem>> heap;
-        for (uint32_t t = 0; t < n_bins; t++) heap.push({0, t});
-        for (uint32_t vi : order) {
-            MGGCN_REQUIRE(!heap.empty(), "sweep plan: task capacity exhausted");
-            const HeapItem top = heap.top();
-            heap.pop();
-            const uint32_t t = top.second;
-            auto &bin = bins[bin_of(t)];
-            bin.push_back(vi);
-            load[t] += vrows[vi].len();
-            if (bin.size() < (size_t)cap_rows) heap.push({load[t], t});
-        }
-    };
-    if (XS == 1) {
-        for (uint32_t r = 0; r < n_rows; r++) {
-            const uint32_t b = indptr[r], e = indptr[r + 1];
-            MGGCN_REQUIRE(e >= b, "indptr must be non-decreasing");
-            const uint32_t len = e - b;
-            if (len <= split + split / 2) {
-                vrows.push_back({r, b, e, r, 1u});
-            } else {
-                // A heavy row is cut into INTERLEAVED slices (slice k = entries k, k + parts, k + 2 parts, ...), not into
-                // contiguous ranges: a dataset written by scipy / the reference's prep.py, and every transposed matrix, holds
-                // its rows sorted by column, so a contiguous slice covers 1 / parts of the column space -- its wave sweeps
-                // a few panels only, out of step with every other wave of the chip (the premise of the sweep).  Measured on
-                // the symmetric Reddit stand-in: d = 128 SpMM 3.09 ms with contiguous slices against 2.36 with the same
-                // rows shuffled (profiles/experiments/symmetric_r03_*.log); interleaved, every slice sees the whole column
-                // distribution of its row whatever the order.
-                const uint32_t parts = (len + split - 1) / split;
-                split_rows.push_back({r, n_slots, parts, 0});
-                for (uint32_t k = 0; k < parts; k++) vrows.push_back({r, b + k, e, kSlotFlag | n_slots++, parts});
-            }
-        }
-        // 2. tasks
-        T = (uint32_t)((vrows.size() + cap_rows - 1) / cap_rows);
-        if (T > round_tasks) T = (T + round_tasks - 1) / round_tasks * round_tasks;
-        T = std::max<uint32_t>(T, 1u);
-        bins.resize(T);
-        std::vector<uint32_t> all(vrows.size());
-        for (size_t i = 0; i < all.size(); i++) all[i] = (uint32_t)i;
-        lpt(all, T, [](uint32_t t) { return t; });
-    } else {
-        // regroup every row's entries by column slice (stable): sub-row (r, s) = [sub[r*XS+s], sub[r*XS+s+1])
-        idx2.resize(nnz);
-        val2.resize(nnz);
-        std::vector<uint32_t> sub((size_t)n_rows * XS + 1, 0u);
-        for (uint32_t r = 0; r < n_rows; r++)
-            for (uint32_t e = indptr[r]; e < indptr[r + 1]; e++) {
-                MGGCN_REQUIRE(indices[e] < n_cols, "column index out of range");
-                sub[(size_t)r * XS + indices[e] / xs_width + 1]++;
-            }
-        for (size_t k = 0; k + 1 < sub.size(); k++) sub[k + 1] += sub[k];
-        {
-            std::vector<uint32_t> cur(sub.begin(), sub.end() - 1);
-            for (uint32_t r = 0; r < n_rows; r++)
-                for (uint32_t e = indptr[r]; e < indptr[r + 1]; e++) {
-                    const uint32_t at = cur[(size_t)r * XS + indices[e] / xs_width]++;
-                    idx2[at] = indices[e];
-                    val2[at] = values[e];
-                }
-        }
-        ix = idx2.data();
-        vv = val2.data();
-        const uint32_t t_est_x = (uint32_t)(((uint64_t)n_rows * XS + cap_rows - 1) / cap_rows);
-        const uint32_t split_x = std::max<uint32_t>(256u, (uint32_t)std::max<uint64_t>(1, nnz / t_est_x) / 2);
-        std::vector<std::vector<uint32_t>> by_slice(XS);
-        for (uint32_t r = 0; r < n_rows; r++) {
-            const uint32_t first = n_slots;
-            for (uint32_t sl = 0; sl < XS; sl++) {
-                const uint32_t b = sub[(size_t)r * XS + sl], e = sub[(size_t)r * XS + sl + 1], len = e - b;
-                if (!len) continue;
-                const uint32_t parts = len <= split_x + split_x / 2 ? 1u : (len + split_x - 1) / split_x;
-                for (uint32_t k = 0; k < parts; k++) {
-                    by_slice[sl].push_back((uint32_t)vrows.size());
-                    vrows.push_back({r, b + k, e, kSlotFlag | n_slots++, parts});
-                }
-            }
-            split_rows.push_back({r, first, n_slots - first, 0});        // every row is combined from its slices (0 slots: C = beta C)
-        }
-        uint32_t Ts = 1;
-        for (const auto &m : by_slice) Ts = std::max<uint32_t>(Ts, (uint32_t)((m.size() + cap_rows - 1) / cap_rows));
-        const uint32_t per_round = round_tasks / XS;                      // tasks of one slice per launch
-        Ts = Ts > per_round ? (Ts + per_round - 1) / per_round * per_round : (Ts + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
-        T = Ts * XS;
-        bins.resize(T);
-        // task q of slice sl sits in block (q / 4) * XS + sl: the dispatcher deals block b to XCD b mod 8
-        for (uint32_t sl = 0; sl < XS; sl++)
-            lpt(by_slice[sl], Ts, [&](uint32_t q) { return ((q / kWavesPerBlock) * XS + sl) * kWavesPerBlock + q % kWavesPerBlock; });
-    }
-    auto task_col_base = [&](uint32_t t) { return XS == 1 ? 0u : ((t / kWavesPerBlock) % XS) * xs_width; };
-    // 3. entry stream per task, sorted by (column panel, local row), original order inside a run.
-    //    Every (panel,row) run is padded to an EVEN number of entries (a zero-valued copy of its
-    //    last entry) and the two entries of each consecutive pair are ordered by column: the
-    //    float4 kernel gathers one pair per instruction, one entry per half-wave.
-    const uint32_t n_panels = ((XS == 1 ? n_cols : xs_width) + panel_rows - 1) / panel_rows;
-    unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-    if (const char *s = std::getenv("MGGCN_HOST_THREADS")) hw = std::max(1u, (unsigned)std::strtoul(s, nullptr, 10));
-    // threads from 2^19 non-zeros on: a rank's blocks at P = 8 on the Reddit shape hold 1.8-3.2 M each, and the 160 plans of
-    // the single-process form were 5 s of one-thread work inside the first epoch
-    const unsigned NT = nnz > (1u << 19) ? hw : 1u;
-    auto run_parallel = [&](auto &&fn) {
-        if (NT <= 1) { fn(0u); return; }
-        std::vector<std::thread> th;
-        for (unsigned i = 0; i < NT; i++) th.emplace_back(fn, i);
-        for (auto &x : th) x.join();
-    };
-    const size_t n_buckets = (size_t)n_panels * kRW;
-    auto count_buckets = [&](uint32_t t, std::vector<uint32_t> &cnt) {
-        std::fill(cnt.begin(), cnt.end(), 0u);
-        const auto &bin = bins[t];
-        const uint32_t base = task_col_base(t);
-        for (size_t r = 0; r < bin.size(); r++) {
-            const VRow &v = vrows[bin[r]];
-            for (uint32_t e = v.beg; e < v.end; e += v.step) {
-                MGGCN_REQUIRE(ix[e] < n_cols, "column index out of range");
-                cnt[(size_t)((ix[e] - base) / panel_rows) * kRW + r]++;
-            }
-        }
-    };
-    // candidate forms: this lpe and every wider one (4 -> 16 entries per instruction, 8 -> 8, 12 -> 5, 16 -> 4)
-    static const uint32_t kLpes[4] = {4u, 8u, 12u, 16u};
-    std::vector<uint32_t> cand;
-    if (narrow) {
-        const uint32_t forced = env_u32("MGGCN_SPMM_NARROW_LPE", 0u);
-        for (uint32_t l : kLpes)
-            if (l >= lpe && (!forced || l == forced)) cand.push_back(l);
-        if (cand.empty()) cand.push_back(lpe);
-    }
-    const size_t NC = narrow ? cand.size() : 1;
-    std::vector<uint64_t> plen_c((size_t)T * NC, 0);
-    run_parallel([&](unsigned tid) {
-        std::vector<uint32_t> cnt(n_buckets);
-        for (uint32_t t = tid; t < T; t += NT) {
-            count_buckets(t, cnt);
-            for (size_t k = 0; k < NC; k++) {
-                const uint32_t g = narrow ? 64u / cand[k] : G;
-                uint64_t len = 0;
-                for (uint32_t c : cnt) len += (c + g - 1) / g * g;
-                plen_c[(size_t)t * NC + k] = len;
-            }
-        }
-    });
-    size_t pick = 0;
-    if (narrow) {
-        // cost of one gather instruction ~ 3 + 2.7 cycles per 128-byte line touched (fitted:
-        // profiles/experiments/narrow_backward.py -- at d = 41 five rows per instruction are no faster
-        // than four on the even-row forward matrix, 13 % slower on the power-law backward one; at
-        // d = 16 sixteen rows per instruction are 1.5x faster than four); rows are pitched to a
-        // multiple of 64 bytes
-        const double lines = std::max(1.0, std::ceil(((d_hint + 15) / 16 * 64) / 128.0));
-        double best = 0;
-        for (size_t k = 0; k < NC; k++) {
-            const uint32_t g = 64u / cand[k];
-            uint64_t tot = 0;
-            for (uint32_t t = 0; t < T; t++) tot += plen_c[(size_t)t * NC + k];
-            const double cost = (double)tot * (3.0 + 2.7 * lines * g) / g;
-            if (k == 0 || cost < best) { best = cost; pick = k; }
-        }
-        lpe = cand[pick];
-        G = 64u / lpe;
-    }
-    // task streams are whole steps of the narrow kernel (4 G entries) AND whole 8-entry batches of the others
-    const uint32_t batch_pad = !narrow ? 8u : (G == 5u ? 40u : std::max(4u * G, 8u));
-    std::vector<uint64_t> plen(T, 0);
-    for (uint32_t t = 0; t < T; t++) plen[t] = plen_c[(size_t)t * NC + pick];
-    std::vector<uint64_t>().swap(plen_c);
-    std::vector<SweepTask> tasks(T);
-    std::vector<uint32_t> task_rows((size_t)T * kRW, 0u);
-    uint64_t off = 0;
-    for (uint32_t t = 0; t < T; t++) {
-        tasks[t].beg = (uint32_t)off;
-        off += (plen[t] + batch_pad - 1) / batch_pad * batch_pad;   // whole 64-byte batches (two per step in the quad form)
-        tasks[t].end = (uint32_t)off;
-        tasks[t].n_rows = (uint32_t)bins[t].size();
-        tasks[t].pad = 0;
-        for (size_t r = 0; r < bins[t].size(); r++) task_rows[(size_t)t * kRW + r] = vrows[bins[t][r]].dst;
-    }
-    MGGCN_REQUIRE(off < (1ull << 32), "sweep plan: entry stream exceeds 32-bit offsets");
-    std::vector<uint2> entries(off);
-    run_parallel([&](unsigned tid) {
-        std::vector<uint32_t> cnt(n_buckets), start(n_buckets + 1), cur(n_buckets);
-        for (uint32_t t = tid; t < T; t += NT) {
-            count_buckets(t, cnt);
-            start[0] = 0;
-            for (size_t k = 0; k < n_buckets; k++) start[k + 1] = start[k] + (cnt[k] + G - 1) / G * G;
-            std::copy(start.begin(), start.begin() + n_buckets, cur.begin());
-            uint2 *out = entries.data() + tasks[t].beg;
-            const auto &bin = bins[t];
-            const uint32_t base = task_col_base(t);
-            for (size_t r = 0; r < bin.size(); r++) {
-                const VRow &v = vrows[bin[r]];
-                for (uint32_t e = v.beg; e < v.end; e += v.step) {
-                    const uint32_t c = ix[e];
-                    const uint32_t at = cur[(size_t)((c - base) / panel_rows) * kRW + r]++;
-                    uint32_t vb;
-                    std::memcpy(&vb, &vv[e], 4);
-                    out[at] = make_uint2((((uint32_t)r & (kRW - 1)) << kColBits) | c, vb);
-                }
-            }
-            for (size_t k = 0; k < n_buckets; k++) {
-                if (!cnt[k]) continue;
-                const uint32_t s0 = start[k], s1 = start[k + 1];
-                for (uint32_t q = s0 + cnt[k]; q < s1; q++) out[q] = make_uint2(out[s0 + cnt[k] - 1].x, 0u);   // pad the run
-                if (G % 2 == 0)
-                    for (uint32_t q = s0; q < s1; q += 2)                            // pair: lower column first
-                        if ((out[q].x & kColMask) > (out[q + 1].x & kColMask)) std::swap(out[q], out[q + 1]);
-                out[s0].x |= kRunFlag;                                               // first entry of the run
-            }
-            // tail padding up to the 8-entry batch: zero-valued copies of the last entry, no run flag
-            const uint32_t real = (uint32_t)plen[t], padded = tasks[t].end - tasks[t].beg;
-            for (uint32_t k = real; k < padded; k++) out[k] = make_uint2(out[real - 1].x & ~kRunFlag, 0u);
-        }
-    });
-
+    static_assert(sizeof(Entry) == sizeof(uint2), "the entry stream is uploaded as is");
+    SweepHost h;
+    if (!sweep_build_host(n_rows, n_cols, indptr, indices, values, max_d, force, d_hint, hot_columns, device_compute_units(), h))
+        return nullptr;
     auto *p = new SweepPlan;
-    p->n_rows = n_rows; p->n_cols = n_cols; p->max_d = max_d;
-    p->n_tasks = T; p->round_tasks = round_tasks; p->run_pad = G; p->lpe = lpe;
-    p->n_split_rows = (uint32_t)split_rows.size(); p->n_slots = n_slots;
-    p->panel_rows = panel_rows; p->n_entries = off;
-    {   // priority rotation (float4 kernels; see rotate_priority): period 2^8 entries / every chunk of the narrow stream
-        const uint32_t rot = env_u32("MGGCN_SPMM_PRIO_ROTATE", 1u) ? kFlagPrioRotate : 0u;
-        p->prio_bits_wide = rot | (std::min(env_u32("MGGCN_SPMM_PRIO_SHIFT", 8u), 15u) << kPrioShiftPos);
-        p->prio_bits_narrow = rot | (std::min(env_u32("MGGCN_SPMM_PRIO_SHIFT_NARROW", 1u), 15u) << kPrioShiftPos);
-        p->tasks_per_wave = std::max(1u, env_u32("MGGCN_SPMM_TASKS_PER_WAVE", 1u));
-        p->allow_quad = env_u32("MGGCN_SPMM_SWEEP_QUAD", 1u) != 0;
-        p->allow_vec4 = env_u32("MGGCN_SPMM_SWEEP_VEC4", 1u) != 0;
-        p->fast_pairs = env_u32("MGGCN_SPMM_FAST_PAIRS", 1u) != 0;
-    }
-    const size_t tb = tasks.size() * sizeof(SweepTask), eb = entries.size() * sizeof(uint2);
-    const size_t rb = task_rows.size() * sizeof(uint32_t), sb = split_rows.size() * sizeof(SweepSplitRow);
-    const size_t pb = (size_t)n_slots * max_d * sizeof(float);
+    p->n_rows = h.n_rows; p->n_cols = h.n_cols; p->max_d = h.max_d;
+    p->n_tasks = h.n_tasks; p->round_tasks = h.round_tasks; p->run_pad = h.run_pad; p->lpe = h.lpe;
+    p->n_split_rows = (uint32_t)h.split_rows.size(); p->n_slots = h.n_slots;
+    p->panel_rows = h.panel_rows; p->n_entries = h.n_entries; p->num_cu = h.num_cu;
+    p->prio_bits_wide = h.prio_bits_wide; p->prio_bits_narrow = h.prio_bits_narrow; p->tasks_per_wave = h.tasks_per_wave;
+    p->allow_quad = h.allow_quad; p->allow_vec4 = h.allow_vec4; p->fast_pairs = h.fast_pairs;
+    const size_t tb = h.tasks.size() * sizeof(SweepTask), eb = h.entries.size() * sizeof(uint2);
+    const size_t rb = h.task_rows.size() * sizeof(uint32_t), sb = h.split_rows.size() * sizeof(SweepSplitRow);
+    const size_t pb = (size_t)h.n_slots * max_d * sizeof(float);
     MGGCN_CHECK_HIP(hipMalloc(&p->d_tasks, tb));
-    MGGCN_CHECK_HIP(hipMemcpy(p->d_tasks, tasks.data(), tb, hipMemcpyHostToDevice));
+    MGGCN_CHECK_HIP(hipMemcpy(p->d_tasks, h.tasks.data(), tb, hipMemcpyHostToDevice));
     MGGCN_CHECK_HIP(hipMalloc(&p->d_entries, eb + 2048));          // + a chunk: the LDS-staged kernel reads whole 1 KiB chunks
     MGGCN_CHECK_HIP(hipMemset(reinterpret_cast<char *>(p->d_entries) + eb, 0, 2048));
-    if (eb) MGGCN_CHECK_HIP(hipMemcpy(p->d_entries, entries.data(), eb, hipMemcpyHostToDevice));
+    if (eb) MGGCN_CHECK_HIP(hipMemcpy(p->d_entries, h.entries.data(), eb, hipMemcpyHostToDevice));
     MGGCN_CHECK_HIP(hipMalloc(&p->d_task_rows, rb));
-    MGGCN_CHECK_HIP(hipMemcpy(p->d_task_rows, task_rows.data(), rb, hipMemcpyHostToDevice));
+    MGGCN_CHECK_HIP(hipMemcpy(p->d_task_rows, h.task_rows.data(), rb, hipMemcpyHostToDevice));
     if (sb) {
         MGGCN_CHECK_HIP(hipMalloc(&p->d_split, sb));
-        MGGCN_CHECK_HIP(hipMemcpy(p->d_split, split_rows.data(), sb, hipMemcpyHostToDevice));
+        MGGCN_CHECK_HIP(hipMemcpy(p->d_split, h.split_rows.data(), sb, hipMemcpyHostToDevice));
     }
     if (pb) MGGCN_CHECK_HIP(hipMalloc(&p->d_partial, pb));
     if (env_u32("MGGCN_SPMM_STAMPS", 0u)) {
-        MGGCN_CHECK_HIP(hipMalloc(&p->d_stamps, (size_t)T * 3 * sizeof(unsigned long long)));
-        MGGCN_CHECK_HIP(hipMemset(p->d_stamps, 0, (size_t)T * 3 * sizeof(unsigned long long)));
+        MGGCN_CHECK_HIP(hipMalloc(&p->d_stamps, (size_t)h.n_tasks * 3 * sizeof(unsigned long long)));
+        MGGCN_CHECK_HIP(hipMemset(p->d_stamps, 0, (size_t)h.n_tasks * 3 * sizeof(unsigned long long)));
     }
     p->bytes = tb + eb + rb + sb + pb;
     return p;
@@ -1136,7 +819,7 @@ uint32_t sweep_plan_launches(const SweepPlan *p, uint32_t d) {
     const bool vec4 = p->run_pad % 2 == 0 && d >= 96 && d % 4 == 0;
     const bool vec2 = d > 64 && d % 2 == 0;
     const uint32_t tpw = (vec4 && !quad) ? p->tasks_per_wave : 1u;
-    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks * tpw : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
+    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks * tpw : std::max(p->round_tasks, p->num_cu * 6u * kWavesPerBlock);
     return (p->n_tasks + per_launch - 1) / per_launch + (p->n_split_rows ? 1u : 0u);
 }
 
@@ -1183,7 +866,7 @@ void sweep_launch(hipStream_t st, const SweepPlan *p, const float *B, size_t ldb
     // of step: d = 41 1.64 / 1.71 ms against 1.52 / 1.55).  The one-column-per-lane kernels (56 VGPRs)
     // are instruction-bound and take six blocks per CU (d = 41: 2.4 -> 2.0 ms).
     const uint32_t tpw = (vec4 && !quad) ? p->tasks_per_wave : 1u;
-    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks * tpw : std::max(p->round_tasks, kNumCU * 6u * kWavesPerBlock);
+    const uint32_t per_launch = (vec2 || vec4 || quad) ? p->round_tasks * tpw : std::max(p->round_tasks, p->num_cu * 6u * kWavesPerBlock);
     // the knobs (priority rotation, tasks per wave, kernel gates) were read once, when the plan was built
     const uint32_t wide_flags = (flags & 0xFFu) | p->prio_bits_wide;
     const uint32_t narrow_flags = (flags & 0xFFu) | p->prio_bits_narrow;

@@ -215,9 +215,14 @@ def gloo_all_gather_rows(host_shard, P: int, group=None):
     """[rows x d] per rank -> [P*rows x d] on every rank, rank order (== ncclAllGather /
     the P broadcasts of reference src/dist_matrix.hpp:458-467)."""
     torch, dist = _torch(), _dist()
-    parts = [torch.empty_like(host_shard) for _ in range(P)]
-    dist.all_gather(parts, host_shard.contiguous(), group=group)
-    return torch.cat(parts, dim=0)
+    # ONE output tensor: gloo's list form of all_gather (P output tensors + a concatenation) is 4x slower at these sizes
+    # -- 28 ms against 6.5 ms for four ranks x [2912 x 128] on loopback, the same as P broadcasts
+    # (profiles/experiments/gloo_allgather_r04.log).  That, not plan building, was the 45.9 ms against 12.4 / 9.8 ms of
+    # the all-gather schedule in the round-3 rehearsals (28 exchanges per epoch); the RCCL path never took this branch.
+    host_shard = host_shard.contiguous()
+    out = torch.empty((P * host_shard.shape[0],) + tuple(host_shard.shape[1:]), dtype=host_shard.dtype)
+    dist.all_gather_into_tensor(out, host_shard, group=group)
+    return out
 
 
 def gloo_broadcast_rows(host_shard, shape, dtype, root: int, rank: int, group=None):

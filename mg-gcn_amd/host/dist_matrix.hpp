@@ -2,10 +2,11 @@
 //
 // Same names as the reference's src/dist_matrix.hpp: dist_context (:12-90),
 // dist_row_csr_matrix (:170-260), dist_row_dn_matrix (:394-532), repl_dn_matrix (:534-639).
-// One host thread drives P GPUs through per-GPU contexts; collectives go through
-// libmggcn_comm.so (include/mggcn_comm.h: RCCL, or event-ordered peer copies when ranks share
-// a GPU).  The column-partition classes (dist_csr_matrix, dist_dn_matrix) are dead code in the
-// reference (only reachable from a commented-out branch of main.cpp) and are not rebuilt.
+// One process drives P GPUs through per-GPU contexts -- by default with one enqueue thread per GPU
+// (enqueue.hpp; the reference's loops `for j: ctx[j].set(); launch` push GPU j's body to thread j);
+// collectives go through libmggcn_comm.so (include/mggcn_comm.h: RCCL, or event-ordered peer copies).
+// The column-partition classes (dist_csr_matrix, dist_dn_matrix) are dead code in the reference (only
+// reachable from a commented-out branch of main.cpp) and are not rebuilt.
 #pragma once
 
 #include <algorithm>
@@ -17,12 +18,16 @@
 #include <thread>
 #include <vector>
 
+#include "enqueue.hpp"
 #include "matrix.hpp"
 #include "mggcn_comm.h"
 
 class dist_context {
     std::vector<context> contexts;
     std::shared_ptr<mggcn_comm> comm_;
+    // one enqueue thread per GPU (enqueue.hpp); null: the calling thread issues everything itself, GPU after GPU,
+    // like the reference (src/cuda_utils.hpp:57-92).  Shared by the copies of a context (contexts are passed by value).
+    std::shared_ptr<mggcn::enqueue_pool> pool_;
 
 public:
     bool overlap = true;
@@ -33,6 +38,7 @@ public:
     // Rank i drives GPU i (reference :26-31).  MGGCN_OVERSUBSCRIBE=1 wraps the ranks over the GPUs that
     // are visible (rank i -> GPU i mod count): the whole P-rank schedule on fewer GPUs, with the
     // communication library's peer-copy transport -- a rehearsal / debugging aid, not a fast path.
+    // MGGCN_ENQUEUE_THREADS=0|1 (default: 1 from two ranks on): one enqueue thread per GPU.
     dist_context(std::size_t P, bool overlap = true) : overlap(overlap) {
         const int count = mggcn_device_count();
         const char *os = std::getenv("MGGCN_OVERSUBSCRIBE");
@@ -42,13 +48,31 @@ public:
         for (std::size_t i = 0; i < P; i++) devices.push_back((int)(i % (std::size_t)std::max(count, 1)));
         for (std::size_t i = 0; i < P; i++) contexts.emplace_back((std::size_t)devices[i]);
         comm_ = std::shared_ptr<mggcn_comm>(mggcn_comm_init_all((int)P, devices.data()), &mggcn_comm_destroy);
+        // the host layer releases its send buffers itself, on the compute stream at the end of an SpMM (ops.hpp), and
+        // its remote blocks never read a rank's own piece of the gathered matrix
+        mggcn_comm_set_exchange_flags(comm_.get(), MGGCN_COMM_DEFER_RELEASE | MGGCN_COMM_SKIP_SELF);
+        const char *et = std::getenv("MGGCN_ENQUEUE_THREADS");
+        if (et ? std::atoi(et) != 0 : P > 1)
+            pool_ = std::make_shared<mggcn::enqueue_pool>(P, [devices](std::size_t j) { mggcn_set_device(devices[j]); });
     }
 
     auto size() const { return contexts.size(); }
-    void sync() const { for (const auto &c : contexts) c.sync(); }
     const context &operator[](std::size_t i) const { return contexts[i]; }
     mggcn_comm *comm() const { return comm_.get(); }
     std::string transport() const { return mggcn_comm_transport(comm_.get()); }
+
+    // ---- per-GPU command queues ---------------------------------------------------------------
+    bool threaded() const { return (bool)pool_; }
+    // GPU j's next command: runs f() on rank j's enqueue thread, after everything pushed for j before (or right here
+    // when the context has no threads).  f captures BY VALUE and never holds a dist_context (enqueue.hpp).
+    template <typename F>
+    void on(std::size_t j, F &&f) const {
+        if (pool_) pool_->push(j, std::forward<F>(f));
+        else f();
+    }
+    // every command pushed so far has been issued; rethrows what a command threw
+    void drain() const { if (pool_) pool_->drain(); }
+    void sync() const { drain(); for (const auto &c : contexts) c.sync(); }
 
     std::vector<mggcn_stream_t> streams(std::size_t stream_id) const {
         std::vector<mggcn_stream_t> s;
@@ -56,18 +80,31 @@ public:
         return s;
     }
 
-    void record(const std::string &name, std::size_t stream_id) const { for (const auto &c : contexts) c.record(name, stream_id); }
-    void wait(const std::string &name, std::size_t stream_id) const { for (const auto &c : contexts) c.wait(name, stream_id); }
+    void record(const std::string &name, std::size_t stream_id) const {
+        for (std::size_t j = 0; j < contexts.size(); j++) on(j, [c = contexts[j], name, stream_id] { c.record(name, stream_id); });
+    }
+    void wait(const std::string &name, std::size_t stream_id) const {
+        for (std::size_t j = 0; j < contexts.size(); j++) on(j, [c = contexts[j], name, stream_id] { c.wait(name, stream_id); });
+    }
     void register_timer(const std::string &n, const std::string &b, const std::string &e) const {
-        for (const auto &c : contexts) c.register_timer(n, b, e);
+        for (std::size_t j = 0; j < contexts.size(); j++) on(j, [c = contexts[j], n, b, e] { c.register_timer(n, b, e); });
+    }
+    // stream `stream_id` of every GPU waits until its peers have read what the GPU sent in the exchanges so far
+    // (include/mggcn_comm.h: MGGCN_COMM_DEFER_RELEASE; nothing to do on the rccl transport)
+    void release_sends(std::size_t stream_id) const {
+        if (!pool_) { const auto s = streams(stream_id); mggcn_comm_release(comm_.get(), s.data()); return; }
+        for (std::size_t j = 0; j < contexts.size(); j++)
+            on(j, [cm = comm_, j, st = contexts[j].stream(stream_id)] { mggcn_comm_release_rank(cm.get(), (int)j, st); });
     }
     std::vector<float> measure(const std::string &name) const {
+        drain();
         std::vector<float> t;
         for (const auto &c : contexts) t.push_back(c.measure(name));
         return t;
     }
     // "<prefix><rank>_<name>:<ms>" (reference :86-89)
     void dump_timers(std::ostream &out, const std::string &prefix = "") const {
+        drain();
         for (std::size_t i = 0; i < size(); i++) contexts[i].dump_timers(out, prefix + std::to_string(i) + "_");
     }
 };
@@ -300,31 +337,48 @@ public:
 
     // shard i to every GPU's bAs[j] (reference :458-467: group of P ncclBroadcast)
     void bcast(const dist_context &ctx, std::size_t i, const dist_row_dn_matrix &bAs, int stream_id = 1) const {
-        std::vector<float *> recv;
-        for (std::size_t j = 0; j < size(); j++) recv.push_back(bAs[j].buffer());
-        const auto streams = ctx.streams(stream_id);
-        mggcn_comm_broadcast_f32(ctx.comm(), As[i].buffer(), recv.data(), As[i].size(), (int)i, streams.data());
+        auto recv = std::make_shared<std::vector<float *>>();
+        for (std::size_t j = 0; j < size(); j++) recv->push_back(bAs[j].buffer());
+        const float *root = As[i].buffer();
+        const std::size_t count = As[i].size();
+        if (!ctx.threaded()) {
+            const auto streams = ctx.streams(stream_id);
+            mggcn_comm_broadcast_f32(ctx.comm(), root, recv->data(), count, (int)i, streams.data());
+            return;
+        }
+        for (std::size_t j = 0; j < size(); j++)
+            ctx.on(j, [cm = ctx.comm(), j, root, recv, count, i, st = ctx[j].stream(stream_id)] {
+                mggcn_comm_broadcast_rank_f32(cm, (int)j, root, recv->data(), count, (int)i, st);
+            });
     }
 
     // rows [row_begin, row_end) of EVERY shard to every GPU, rank order, at gathered[j] + P * row_begin * m:
     // one piece of the MI355X-first exchange (the whole shard when the range is the whole shard)
     void allgather(const dist_context &ctx, const std::vector<matrix_t> &gathered, std::size_t row_begin, std::size_t row_end,
                    int stream_id = 1) const {
-        std::vector<const float *> send;
-        std::vector<float *> recv;
+        auto send = std::make_shared<std::vector<const float *>>();
+        auto recv = std::make_shared<std::vector<float *>>();
         const std::size_t P = size(), w = m();
         for (std::size_t j = 0; j < P; j++) {
-            send.push_back(As[j].buffer() + row_begin * w);
-            recv.push_back(gathered[j].buffer() + P * row_begin * w);
+            send->push_back(As[j].buffer() + row_begin * w);
+            recv->push_back(gathered[j].buffer() + P * row_begin * w);
         }
-        const auto streams = ctx.streams(stream_id);
-        mggcn_comm_allgather_f32(ctx.comm(), send.data(), recv.data(), (row_end - row_begin) * w, streams.data());
+        const std::size_t count = (row_end - row_begin) * w;
+        if (!ctx.threaded()) {
+            const auto streams = ctx.streams(stream_id);
+            mggcn_comm_allgather_f32(ctx.comm(), send->data(), recv->data(), count, streams.data());
+            return;
+        }
+        for (std::size_t j = 0; j < P; j++)
+            ctx.on(j, [cm = ctx.comm(), j, send, recv, count, st = ctx[j].stream(stream_id)] {
+                mggcn_comm_allgather_rank_f32(cm, (int)j, send->data(), recv->data(), count, st);
+            });
     }
     void allgather(const dist_context &ctx, const std::vector<matrix_t> &gathered, int stream_id = 1) const {
         allgather(ctx, gathered, 0, As[0].n(), stream_id);
     }
 
-    void zero(const dist_context &ctx) const { for (std::size_t i = 0; i < size(); i++) As[i].zero(ctx[i]); }
+    void zero(const dist_context &ctx) const { for (std::size_t i = 0; i < size(); i++) ctx.on(i, [c = ctx[i], a = As[i]] { a.zero(c); }); }
 
     void to_dn_matrix(const dist_context &ctx, std::vector<r_t> &host) const {
         ctx.sync();
@@ -364,10 +418,18 @@ public:
 
     // in-place sum over the GPUs (reference :587-592), on stream `stream_id` of every GPU
     void allreduce(const dist_context &ctx, int stream_id = 0) const {
-        std::vector<float *> bufs;
-        for (const auto &A : As) bufs.push_back(A.buffer());
-        const auto streams = ctx.streams(stream_id);
-        mggcn_comm_allreduce_sum_f32(ctx.comm(), bufs.data(), As[0].size(), streams.data());
+        auto bufs = std::make_shared<std::vector<float *>>();
+        for (const auto &A : As) bufs->push_back(A.buffer());
+        const std::size_t count = As[0].size();
+        if (!ctx.threaded()) {
+            const auto streams = ctx.streams(stream_id);
+            mggcn_comm_allreduce_sum_f32(ctx.comm(), bufs->data(), count, streams.data());
+            return;
+        }
+        for (std::size_t j = 0; j < As.size(); j++)
+            ctx.on(j, [cm = ctx.comm(), j, bufs, count, st = ctx[j].stream(stream_id)] {
+                mggcn_comm_allreduce_sum_rank_f32(cm, (int)j, bufs->data(), count, st);
+            });
     }
 
     // the reference initialises GPU 0 and broadcasts (:601-609); the seed-99 host generator
@@ -378,5 +440,5 @@ public:
     void fill(const dist_context &ctx, r_t v) {
         for (std::size_t i = 0; i < As.size(); i++) { ctx[i].set(); As[i].fill(v); }
     }
-    void zero(const dist_context &ctx) const { for (std::size_t i = 0; i < As.size(); i++) As[i].zero(ctx[i]); }
+    void zero(const dist_context &ctx) const { for (std::size_t i = 0; i < As.size(); i++) ctx.on(i, [c = ctx[i], a = As[i]] { a.zero(c); }); }
 };

@@ -78,7 +78,7 @@ class dist_sparse_linear {
             case dist_mode::rounds: matmul(ctx, Mx, B, C, e, round_views(ctx, B), (r_t)1, beta, name + tag, flags); break;
             case dist_mode::allgather: matmul_allgather(ctx, Mx, B, C, e, gather_views(ctx, B), (r_t)1, beta, name + tag, flags); break;
             case dist_mode::halo:
-                if (!hp) hp = std::make_shared<dist_halo_plan<r_t>>(ctx, Mx);
+                if (!hp) { ctx.drain(); hp = std::make_shared<dist_halo_plan<r_t>>(ctx, Mx); }
                 matmul_halo(ctx, Mx, B, C, e, *hp, gather_views(ctx, B), (r_t)1, beta, name + tag, flags);
                 break;
         }
@@ -264,13 +264,18 @@ public:
     }
 
     void backward(dist_context ctx, dn_t G, dn_t G_out, bool discard = true, const dn_t *mask = nullptr) {
-        if (ones.size() != ctx.size() || ones.m() != G.n() / ctx.size()) { ones = rdn_t(ctx, 1, G.n() / ctx.size()); ones.fill(ctx, 1); }
+        if (!fused && (ones.size() != ctx.size() || ones.m() != G.n() / ctx.size())) { ctx.drain(); ones = rdn_t(ctx, 1, G.n() / ctx.size()); ones.fill(ctx, 1); }
         const int cs = ctx.bcast_stream_id();
         ctx.record(name + "1_0_matmul-gemm", 0);
         for (std::size_t i = 0; i < ctx.size(); i++) {
-            if (fused) { linear_backward_weights(ctx[i], X[i], G[i], G_W[i], G_b[i]); continue; }
-            matmul(ctx[i], ones[i], G[i], G_b[i], (r_t)1, (r_t)0);            // G_b = 1^T G      (local part)
-            matmul(ctx[i], X[i], G[i], G_W[i], (r_t)1, (r_t)0, true);         // G_W = X^T G      (local part)
+            if (fused) {
+                ctx.on(i, [c = ctx[i], x = X[i], g = G[i], gw = G_W[i], gb = G_b[i]] { linear_backward_weights(c, x, g, gw, gb); });
+                continue;
+            }
+            ctx.on(i, [c = ctx[i], o = ones[i], x = X[i], g = G[i], gw = G_W[i], gb = G_b[i]] {
+                matmul(c, o, g, gb, (r_t)1, (r_t)0);                          // G_b = 1^T G      (local part)
+                matmul(c, x, g, gw, (r_t)1, (r_t)0, true);                    // G_W = X^T G      (local part)
+            });
         }
         ctx.record(name + "1_1_grad-local", 0);
         ctx.wait(name + "1_1_grad-local", cs);
@@ -279,7 +284,8 @@ public:
         pending = true;
         ctx.record(name + "1_2_matmul-gemm", 0);
         if (backward_out && mask)
-            for (std::size_t i = 0; i < ctx.size(); i++) matmul_lrelu_backward(ctx[i], G[i], W[i], (*mask)[i], G_out[i], (r_t)1, false, true);
+            for (std::size_t i = 0; i < ctx.size(); i++)
+                ctx.on(i, [c = ctx[i], g = G[i], w = W[i], z = (*mask)[i], go = G_out[i]] { matmul_lrelu_backward(c, g, w, z, go, (r_t)1, false, true); });
         else if (backward_out) matmul(ctx, G, W, G_out, (r_t)1, discard ? (r_t)0 : (r_t)1, true);
         ctx.record(name + "1_3_matmul-gemm", 0);
         ctx.register_timer(name + "1_matmul-gemm", name + "1_0_matmul-gemm", name + "1_3_matmul-gemm");
@@ -312,7 +318,10 @@ public:
         step += 1;
         ctx.record(name + "0_adam-update", 0);
         for (std::size_t i = 0; i < ctx.size(); i++)
-            adam_step(ctx[i], fused, W[i], G_W[i], mW[i], vW[i], b[i], G_b[i], mb[i], vb[i], lr, beta1, beta2, weight_decay, eps, step);
+            ctx.on(i, [c = ctx[i], f = fused, w = W[i], gw = G_W[i], mw = mW[i], vw = vW[i], bb = b[i], gb = G_b[i], m_b = mb[i], v_b = vb[i],
+                       lr, beta1, beta2, weight_decay, eps, st = step] {
+                adam_step(c, f, w, gw, mw, vw, bb, gb, m_b, v_b, lr, beta1, beta2, weight_decay, eps, st);
+            });
         ctx.record(name + "1_adam-update", 0);
         ctx.register_timer(name + "adam-update", name + "0_adam-update", name + "1_adam-update");
     }
@@ -499,13 +508,15 @@ public:
             ctx.register_timer(name + "0_activation", name + "0_0_activation", name + "0_1_activation");
         }
         if (res_lin) (*res_lin)(ctx, H, AHW, false);          // reference :572-575
-        else if (residual_layer) for (std::size_t i = 0; i < ctx.size(); i++) axpy(ctx[i], H[i], AHW[i], (r_t)1);
+        else if (residual_layer)
+            for (std::size_t i = 0; i < ctx.size(); i++) ctx.on(i, [c = ctx[i], h = H[i], a = AHW[i]] { axpy(c, h, a, (r_t)1); });
         return AHW;
     }
 
     dn_t residual_backward(dist_context ctx, dn_t G, dn_t out) {      // reference :603-606
         if (res_lin) res_lin->backward(ctx, G, out, false);
-        else if (residual_layer) for (std::size_t i = 0; i < ctx.size(); i++) axpy(ctx[i], G[i], out[i], (r_t)1);
+        else if (residual_layer)
+            for (std::size_t i = 0; i < ctx.size(); i++) ctx.on(i, [c = ctx[i], g = G[i], o = out[i]] { axpy(c, g, o, (r_t)1); });
         return out;
     }
 
@@ -638,7 +649,7 @@ public:
 template <typename r_t, typename x_t>
 class dist_row_softmax_cross_entropy_loss {
     std::string name;
-    std::vector<loss_kernels<r_t, x_t>> ks;
+    std::vector<std::shared_ptr<loss_kernels<r_t, x_t>>> ks;    // one per GPU, shared with the commands in flight
     const bool copy, fused;
     dist_row_dn_matrix<r_t> G;
 
@@ -646,15 +657,16 @@ public:
     dist_row_softmax_cross_entropy_loss(std::string name, bool copy = true, bool fused = false) : name(name), copy(copy), fused(fused) {}
 
     auto operator()(dist_context ctx, dist_row_dn_matrix<r_t> H, dist_row_dn_matrix<x_t> Y) {
-        while (ks.size() < ctx.size()) ks.emplace_back(copy, fused);
+        while (ks.size() < ctx.size()) ks.push_back(std::make_shared<loss_kernels<r_t, x_t>>(copy, fused));
         ctx.record(name + "0_loss-layer", 0);
-        for (std::size_t i = 0; i < ctx.size(); i++) ks[i].enqueue(ctx[i], H[i], Y[i], Y.n());     // global n (reference :908)
+        for (std::size_t i = 0; i < ctx.size(); i++)                                               // global n (reference :908)
+            ctx.on(i, [k = ks[i], c = ctx[i], h = H[i], y = Y[i], n = Y.n()] { k->enqueue(c, h, y, n); });
         ctx.record(name + "1_loss-layer", 0);
         ctx.register_timer(name + "loss-layer", name + "0_loss-layer", name + "1_loss-layer");
         ctx.sync();
         r_t loss = 0, acc = 0;
         for (std::size_t i = 0; i < ctx.size(); i++) {          // host sum of the per-GPU scalars (reference :929)
-            const r_t *s = ks[i].sums();                        // mapped pinned host memory
+            const r_t *s = ks[i]->sums();                       // mapped pinned host memory
             loss += s[0];
             acc += s[1];
         }
@@ -821,13 +833,15 @@ public:
                 std::vector<r_t> w;
                 for (auto &l : layers_)
                     for (auto *lin : l.linears()) lin->adam_tensors(g, t, w, wd);
-                adam_.emplace_back(ctx[g], t, w);
+                adam_.push_back(std::make_shared<adam_table<r_t>>(ctx[g], t, w));
             }
             adam_wd_ = wd;
         }
         ctx.record("0_adam-update", 0);
         for (std::size_t g = 0; g < ctx.size(); g++)
-            adam_[g].step(ctx[g], lr, b1, b2, (r_t)(1 - std::pow(b1, step)), (r_t)(1 - std::pow(b2, step)), eps);
+            ctx.on(g, [t = adam_[g], c = ctx[g], lr, b1, b2, c1 = (r_t)(1 - std::pow(b1, step)), c2 = (r_t)(1 - std::pow(b2, step)), eps] {
+                t->step(c, lr, b1, b2, c1, c2, eps);
+            });
         ctx.record("1_adam-update", 0);
         ctx.register_timer("adam-update", "0_adam-update", "1_adam-update");
     }
@@ -835,6 +849,6 @@ public:
 
 private:
     bool fused_ = true;
-    std::vector<adam_table<r_t>> adam_;
+    std::vector<std::shared_ptr<adam_table<r_t>>> adam_;     // one per GPU, shared with the commands in flight
     r_t adam_wd_ = 0;
 };

@@ -178,6 +178,7 @@ int main_(int argc, char **argv) {
             std::vector<v_t> p(P + 1);
             for (std::size_t i = 1; i < p.size(); i++) p[i] = (v_t)(i * A.n() / P);
             stage("dist_context");
+            if (stage.on) std::cerr << "[mggcn timing] transport " << ctx.transport() << " enqueue-threads " << (int)ctx.threaded() << std::endl;
             A.normalize(true);
             auto A_T = A.transpose();
             stage("normalize + transpose");

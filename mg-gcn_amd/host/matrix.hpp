@@ -248,6 +248,7 @@ public:
             if (!dup) jobs.push_back({w.A.st_, w.dev, form, max_d, (unsigned)w.d});
         }
         const int dev0 = mggcn_get_device();
+        mggcn_spmm_plan_concurrent_builders((std::uint32_t)std::min(jobs.size(), max_parallel));   // each builder threads over its share of the cores
         for (std::size_t lo = 0; lo < jobs.size(); lo += max_parallel) {
             std::vector<std::thread> th;
             for (std::size_t k = lo; k < std::min(jobs.size(), lo + max_parallel); k++)
@@ -259,6 +260,7 @@ public:
                 });
             for (auto &t : th) t.join();
         }
+        mggcn_spmm_plan_concurrent_builders(1);
         for (auto &j : jobs) j.st->plans[{j.dev, j.form}] = {j.max_d, spmm_buffer(j.out, &mggcn_spmm_plan_destroy)};
         mggcn_set_device(dev0);
     }

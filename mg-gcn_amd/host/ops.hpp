@@ -152,6 +152,8 @@ dist_spmm_buffers get_matmul_buffer(const dist_context ctx, const dist_row_csr_m
                                     const dist_row_dn_matrix<r_t> B, const dist_row_dn_matrix<r_t> C, dist_mode mode) {
     dist_spmm_buffers out;
     const auto P = ctx.size();
+    ctx.drain();        // plans and device copies of the blocks are created by the calling thread: no command of an
+                        // enqueue thread may be using the same matrices meanwhile (first epoch only)
     out.block.resize(P);
     out.piece.resize(P);
     {   // every rank's plans of this width, built side by side (csr_matrix::prebuild_plans), then picked up below
@@ -197,8 +199,9 @@ void matmul(dist_context ctx, dist_row_csr_matrix<x_t, v_t, r_t> A, dist_row_dn_
         ctx.record(name + std::to_string(i) + "_matmul-bcast-finish", cs);
         ctx.wait(name + std::to_string(i) + "_matmul-bcast-finish", 0);
         for (std::size_t j = 0; j < P; j++)
-            matmul(ctx[j], A[{j, i}], B_bcast[i % 2][j], C[j], ext.block[j][i], alpha, i == 0 ? beta : (r_t)1,
-                   i + 1 == P ? last_flags : 0u);
+            ctx.on(j, [c = ctx[j], a = A[{j, i}], b = B_bcast[i % 2][j], cc = C[j], pl = ext.block[j][i], alpha,
+                       bt = i == 0 ? beta : (r_t)1, fl = i + 1 == P ? last_flags : 0u] { matmul(c, a, b, cc, pl, alpha, bt, fl); });
+        if (i + 1 == P) ctx.release_sends(0);             // B may be overwritten once every GPU has read its broadcasts
         ctx.record(name + std::to_string(i + 1) + "_matmul-spmm", 0);
     }
     ctx.register_timer(name + "matmul-spmm", name + "0_matmul-spmm", name + std::to_string(P) + "_matmul-spmm");
@@ -223,16 +226,19 @@ void matmul_allgather(dist_context ctx, dist_row_csr_matrix<x_t, v_t, r_t> A, di
         ctx.record(name + std::to_string(c) + "_matmul-bcast-finish", cs);
     }
     for (std::size_t j = 0; j < P; j++)                   // local block: no dependency on the exchange
-        matmul(ctx[j], A[{j, j}], B[j], C[j], ext.block[j][j], alpha, beta, P == 1 ? last_flags : 0u);
+        ctx.on(j, [c = ctx[j], a = A[{j, j}], b = B[j], cc = C[j], pl = ext.block[j][j], alpha, beta,
+                   fl = P == 1 ? last_flags : 0u] { matmul(c, a, b, cc, pl, alpha, beta, fl); });
     for (std::size_t c = 0; c < K; c++) {
         ctx.wait(name + std::to_string(c) + "_matmul-bcast-finish", 0);
         if (P == 1) continue;
         const std::size_t len = cb[c + 1] - cb[c];
         for (std::size_t j = 0; j < P; j++) {
             const dn_matrix<r_t> piece(P * len, d, mggcn::device_view(gathered[j].shared_buffer(), P * cb[c] * d));
-            matmul(ctx[j], A.remote_chunk(j, c), piece, C[j], ext.piece[j][c], alpha, (r_t)1, c + 1 == K ? last_flags : 0u);
+            ctx.on(j, [cx = ctx[j], a = A.remote_chunk(j, c), piece, cc = C[j], pl = ext.piece[j][c], alpha,
+                       fl = c + 1 == K ? last_flags : 0u] { matmul(cx, a, piece, cc, pl, alpha, (r_t)1, fl); });
         }
     }
+    ctx.release_sends(0);                                 // a GPU's shard may be overwritten once its peers have pulled it
     ctx.record(name + "1_matmul-spmm", 0);
     ctx.register_timer(name + "matmul-spmm", name + "0_matmul-spmm", name + "1_matmul-spmm");
 }
@@ -289,33 +295,45 @@ void matmul_halo(dist_context ctx, dist_row_csr_matrix<x_t, v_t, r_t> A, dist_ro
     const std::size_t d = B.m();
     halo.reserve(ctx, d);
     ctx.record(name + "0_matmul-spmm", 0);
-    for (std::size_t j = 0; j < P; j++) {                 // pack on the compute stream
-        ctx[j].set();
+    for (std::size_t j = 0; j < P; j++)                   // pack on the compute stream
         if (halo.send_rows[j])
-            mggcn_gather_rows_f32(ctx[j].stream(0), B[j].buffer(), d, halo.send_idx[j].get(), halo.send_rows[j], (uint32_t)d,
-                                  halo.send_buf[j].get(), d);
-    }
+            ctx.on(j, [c = ctx[j], b = B[j], idx = halo.send_idx[j], rows = halo.send_rows[j], d, out = halo.send_buf[j]] {
+                c.set();
+                mggcn_gather_rows_f32(c.stream(0), b.buffer(), d, idx.get(), rows, (uint32_t)d, out.get(), d);
+            });
     ctx.record(name + "0_matmul-halo-packed", 0);
     ctx.wait(name + "0_matmul-halo-packed", cs);
     ctx.record(name + "0_matmul-bcast-start", cs);
     {
-        std::vector<const float *> send;
-        std::vector<float *> rcv;
-        std::vector<std::size_t> counts(P * P);
-        for (std::size_t j = 0; j < P; j++) { send.push_back(halo.send_buf[j].get()); rcv.push_back(recv[j].buffer()); }
-        for (std::size_t q = 0; q < P * P; q++) counts[q] = halo.rows[q] * d;
-        const auto streams = ctx.streams(cs);
-        mggcn_comm_alltoallv_f32(ctx.comm(), send.data(), rcv.data(), counts.data(), streams.data());
+        struct exchange_args { std::vector<const float *> send; std::vector<float *> rcv; std::vector<std::size_t> counts;
+                               std::vector<mggcn::device_ptr<r_t>> keep; };
+        auto x = std::make_shared<exchange_args>();
+        x->counts.resize(P * P);
+        for (std::size_t j = 0; j < P; j++) { x->send.push_back(halo.send_buf[j].get()); x->rcv.push_back(recv[j].buffer()); x->keep.push_back(halo.send_buf[j]); }
+        for (std::size_t q = 0; q < P * P; q++) x->counts[q] = halo.rows[q] * d;
+        if (!ctx.threaded()) {
+            const auto streams = ctx.streams(cs);
+            mggcn_comm_alltoallv_f32(ctx.comm(), x->send.data(), x->rcv.data(), x->counts.data(), streams.data());
+        } else {
+            for (std::size_t j = 0; j < P; j++)
+                ctx.on(j, [cm = ctx.comm(), j, x, st = ctx[j].stream(cs)] {
+                    mggcn_comm_alltoallv_rank_f32(cm, (int)j, x->send.data(), x->rcv.data(), x->counts.data(), st);
+                });
+        }
     }
     ctx.record(name + "0_matmul-bcast-finish", cs);
     for (std::size_t j = 0; j < P; j++)
-        matmul(ctx[j], A[{j, j}], B[j], C[j], ext.block[j][j], alpha, beta, P == 1 ? last_flags : 0u);
+        ctx.on(j, [c = ctx[j], a = A[{j, j}], b = B[j], cc = C[j], pl = ext.block[j][j], alpha, beta,
+                   fl = P == 1 ? last_flags : 0u] { matmul(c, a, b, cc, pl, alpha, beta, fl); });
     ctx.wait(name + "0_matmul-bcast-finish", 0);
     if (P > 1)
         for (std::size_t j = 0; j < P; j++) {
             const dn_matrix<r_t> r(std::max<std::size_t>(halo.recv_rows[j], 1), d, recv[j].shared_buffer());
-            matmul(ctx[j], A.halo_remote(j), r, C[j], ext.halo[j], alpha, (r_t)1, last_flags);
+            ctx.on(j, [c = ctx[j], a = A.halo_remote(j), r, cc = C[j], pl = ext.halo[j], alpha, last_flags] {
+                matmul(c, a, r, cc, pl, alpha, (r_t)1, last_flags);
+            });
         }
+    ctx.release_sends(0);                                 // the pack buffers are rewritten by the next call
     ctx.record(name + "1_matmul-spmm", 0);
     ctx.register_timer(name + "matmul-spmm", name + "0_matmul-spmm", name + "1_matmul-spmm");
 }
@@ -324,20 +342,23 @@ void matmul_halo(dist_context ctx, dist_row_csr_matrix<x_t, v_t, r_t> A, dist_ro
 template <typename r_t>
 void matmul(const dist_context ctx, const dist_row_dn_matrix<r_t> A, const dist_row_dn_matrix<r_t> B,
             const repl_dn_matrix<r_t> C, const r_t alpha, const r_t beta) {      // C = sum_i A_i^T B_i
-    for (std::size_t i = 0; i < ctx.size(); i++) matmul(ctx[i], A[i], B[i], C[i], alpha, beta, true);
+    for (std::size_t i = 0; i < ctx.size(); i++)
+        ctx.on(i, [c = ctx[i], a = A[i], b = B[i], cc = C[i], alpha, beta] { matmul(c, a, b, cc, alpha, beta, true); });
     C.allreduce(ctx);
 }
 
 template <typename r_t>
 void matmul(const dist_context ctx, const dist_row_dn_matrix<r_t> A, const repl_dn_matrix<r_t> B,
             const dist_row_dn_matrix<r_t> C, const r_t alpha, const r_t beta, const bool B_T = false) {
-    for (std::size_t i = 0; i < ctx.size(); i++) matmul(ctx[i], A[i], B[i], C[i], alpha, beta, false, B_T);
+    for (std::size_t i = 0; i < ctx.size(); i++)
+        ctx.on(i, [c = ctx[i], a = A[i], b = B[i], cc = C[i], alpha, beta, B_T] { matmul(c, a, b, cc, alpha, beta, false, B_T); });
 }
 
 template <typename r_t>
 void linear_forward(const dist_context ctx, const dist_row_dn_matrix<r_t> X, const repl_dn_matrix<r_t> W,
                     const repl_dn_matrix<r_t> b, const dist_row_dn_matrix<r_t> XW) {
-    for (std::size_t i = 0; i < ctx.size(); i++) linear_forward(ctx[i], X[i], W[i], b[i], XW[i]);
+    for (std::size_t i = 0; i < ctx.size(); i++)
+        ctx.on(i, [c = ctx[i], x = X[i], w = W[i], bb = b[i], xw = XW[i]] { linear_forward(c, x, w, bb, xw); });
 }
 
 // ---- BLAS-1 (reference src/cuda_utils.hpp:326-381) -------------------------------------------
@@ -464,13 +485,20 @@ void softmax_xent_fused(const context ctx, const dn_matrix<r_t> H, const dn_matr
 }
 
 // dist_context forms: per-GPU loops, as in the reference's "template<dn_t>" overloads
-#define MGGCN_DIST_LOOP(call) for (std::size_t i = 0; i < ctx.size(); i++) { call; }
 template <typename r_t, template <typename> class dn_t>
-void leaky_relu_forward(const dist_context ctx, const dn_t<r_t> in, const dn_t<r_t> out, r_t a = 0.01) { MGGCN_DIST_LOOP(leaky_relu_forward(ctx[i], in[i], out[i], a)) }
+void leaky_relu_forward(const dist_context ctx, const dn_t<r_t> in, const dn_t<r_t> out, r_t a = 0.01) {
+    for (std::size_t i = 0; i < ctx.size(); i++) ctx.on(i, [c = ctx[i], x = in[i], y = out[i], a] { leaky_relu_forward(c, x, y, a); });
+}
 template <typename r_t, template <typename> class dn_t>
-void leaky_relu_backward(const dist_context ctx, const dn_t<r_t> in, const dn_t<r_t> G_in, const dn_t<r_t> G_out, r_t a = 0.01) { MGGCN_DIST_LOOP(leaky_relu_backward(ctx[i], in[i], G_in[i], G_out[i], a)) }
+void leaky_relu_backward(const dist_context ctx, const dn_t<r_t> in, const dn_t<r_t> G_in, const dn_t<r_t> G_out, r_t a = 0.01) {
+    for (std::size_t i = 0; i < ctx.size(); i++)
+        ctx.on(i, [c = ctx[i], x = in[i], g = G_in[i], y = G_out[i], a] { leaky_relu_backward(c, x, g, y, a); });
+}
 template <typename r_t, template <typename> class d1, template <typename> class d2>
-void broadcast_rows(const dist_context ctx, const d1<r_t> row, const d2<r_t> mat, const bool discard = true) { MGGCN_DIST_LOOP(broadcast_rows(ctx[i], row[i], mat[i], discard)) }
+void broadcast_rows(const dist_context ctx, const d1<r_t> row, const d2<r_t> mat, const bool discard = true) {
+    for (std::size_t i = 0; i < ctx.size(); i++) ctx.on(i, [c = ctx[i], r = row[i], m = mat[i], discard] { broadcast_rows(c, r, m, discard); });
+}
 template <typename r_t, template <typename> class dn_t>
-void scale_mat(const dist_context ctx, const dn_t<r_t> mat, r_t s) { MGGCN_DIST_LOOP(scale_mat(ctx[i], mat[i], s)) }
-#undef MGGCN_DIST_LOOP
+void scale_mat(const dist_context ctx, const dn_t<r_t> mat, r_t s) {
+    for (std::size_t i = 0; i < ctx.size(); i++) ctx.on(i, [c = ctx[i], m = mat[i], s] { scale_mat(c, m, s); });
+}

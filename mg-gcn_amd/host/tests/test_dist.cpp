@@ -9,7 +9,10 @@
 // exchange schedule (allgather in K pieces / halo / the reference's rounds), overlap on and off (-S),
 // fused and reference launch sequences.  P = 1 must reproduce the single-GPU gradients BIT FOR BIT (same
 // kernels on the same operands); P > 1 regroups the sums: 1e-4 relative on the loss and every gradient of BOTH epochs
-// (the second epoch restarts from the single-GPU parameters, see run_dist).
+// (the second epoch restarts from the single-GPU parameters, see run_dist).  Every case runs twice -- one enqueue
+// thread per GPU (host/enqueue.hpp, the default from two ranks on) and the reference's one-thread loops
+// (MGGCN_ENQUEUE_THREADS=0) -- and the two must agree BIT FOR BIT: per GPU the same commands in the same order.
+// test_late_rank: the per-pair ordering of the peer-copy transport and its deferred release (include/mggcn_comm.h).
 #include <cstdint>
 #include <cstdlib>
 #include <string>
@@ -183,10 +186,73 @@ static void compare(std::size_t P, const epoch_result &d, const epoch_result &s,
     }
 }
 
+static bool same_bits(const epoch_result &a, const epoch_result &b) {
+    bool ok = a.W1 == b.W1 && a.b1 == b.b1 && a.W == b.W;
+    for (int e = 0; e < 2; e++) ok = ok && a.loss[e] == b.loss[e] && a.acc[e] == b.acc[e] && a.G_W[e] == b.G_W[e] && a.G_b[e] == b.G_b[e];
+    return ok;
+}
+
+// One rank's comm stream is LATE (a queue of large GEMMs in front of the exchange).  Broadcast of rank 0's shard:
+//   * a receiver that is on time gets its copy without waiting for the late rank (the round-3 transport bracketed every
+//     exchange with an all-streams barrier: everybody finished when the slowest rank had pulled);
+//   * the late rank still receives the ORIGINAL data although the root overwrites its shard right after the exchange:
+//     the root's release (deferred to the stream that overwrites, MGGCN_COMM_DEFER_RELEASE) waits for that reader.
+// Event timestamps on the ranks' own streams; meaningful on the p2p transport (the only one a one-GPU box can run at P > 1).
+static void test_late_rank(std::size_t P) {
+    dist_context ctx(P, true);
+    const int cs = ctx.bcast_stream_id();
+    const std::size_t rows = 64 * P, d = 256, late = P - 1, on_time = 1;
+    std::vector<float> vals(rows * d);
+    for (std::size_t i = 0; i < vals.size(); i++) vals[i] = (float)(i % 1009) + 0.5f;
+    dn_matrix<r_t> host(rows, d);
+    host.init(vals);
+    dist_row_dn_matrix<r_t> B(ctx, host), R(ctx, rows, d);
+    R.zero(ctx);
+    ctx.sync();
+    // the delay: ten 3072^3 products on the late rank's comm stream (several ms)
+    const std::uint32_t g = 3072;
+    ctx[late].set();
+    dn_matrix<r_t> ga(g, g), gb(g, g), gc(g, g);
+    ga.zero(ctx[late]); gb.zero(ctx[late]);
+    ctx.sync();
+    ctx.on(late, [c = ctx[late], ga, gb, gc, g, cs] {
+        c.set();
+        c.record("delay-0", cs);
+        const auto ws = mggcn_gemm_workspace_bytes(0, 0, g, g, g);
+        for (int k = 0; k < 10; k++)
+            mggcn_gemm_f32(c.stream(cs), 0, 0, g, g, g, 1.f, ga.buffer(), g, gb.buffer(), g, 0.f, gc.buffer(), g, c.gemm_workspace(ws), ws);
+        c.record("delay-1", cs);
+    });
+    ctx.record("t0", cs);
+    B.bcast(ctx, 0, R, cs);
+    ctx.record("t1", cs);
+    ctx.register_timer("exchange", "t0", "t1");
+    ctx.on(late, [c = ctx[late]] { c.register_timer("delay", "delay-0", "delay-1"); });
+    ctx.release_sends(0);                                  // the root's compute stream waits for every reader ...
+    B.zero(ctx);                                           // ... and only then overwrites what it sent
+    ctx.sync();
+    const float delay = ctx[late].measure("delay"), t_on_time = ctx[on_time].measure("exchange");
+    const std::vector<float> want(vals.begin(), vals.begin() + (rows / P) * d);
+    for (std::size_t j = 0; j < P; j++) { ctx[j].set(); CHECK(R[j].to_host() == want); }
+    // the timing claim needs the on-time rank's streams on hardware queues of their own: on ONE device that holds up to four ranks
+    const bool timed = ctx.transport() == "p2p" && P <= 4;
+    if (timed) CHECK(t_on_time < 0.5f * delay);
+    std::printf("%s: late rank: delay %.2f ms, on-time receiver's exchange %.3f ms%s, transport %s, threads %d\n",
+                (!timed || t_on_time < 0.5f * delay) ? "TEST PASSED" : "TEST FAILED", delay, t_on_time, timed ? "" : " (not asserted)",
+                ctx.transport().c_str(), (int)ctx.threaded());
+    mggcn_set_device(0);
+}
+
 int main(int argc, char **argv) {
     // test_dist P [n graph_seed F C hidden...]: the defaults are the fixed case of the suite; tests/test_gpu_host_cpp.py also
     // walks a few random shapes (odd widths, one hidden layer, class counts that need padding to a multiple of P)
     const std::size_t P = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1;
+    // Streams are multiplexed over a few hardware queues per device and priority (4 by default) and two streams that share a
+    // queue run one after the other: with P ranks x (compute, comm, P - 1 pulling streams) on ONE device the late rank's
+    // queue of GEMMs holds up whoever shares its hardware queue.  Eight queues keep the ranks of P <= 4 apart (measured,
+    // profiles/experiments/time_dist_tests_r04.log: the suite runs as fast as with four; with 24 the driver time-slices
+    // the queues and the same binary takes 50x as long).  Must be set before the first HIP call.
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const v_t n = argc > 2 ? (v_t)std::strtoull(argv[2], nullptr, 10) : 1536;      // 1536: divisible by 1, 2, 3, 4, 6, 8
     if (P == 0 || n % P != 0) { std::fprintf(stderr, "P must divide %u\n", n); return 2; }
     mggcn_set_device(0);
@@ -210,16 +276,29 @@ int main(int argc, char **argv) {
         const auto single = run_single(csr_matrix<x_t, v_t, r_t>(A.indptr(), A.indices(), A.data(), A.m()), sizes, X, Y, fused);
         for (const auto mode : {dist_mode::allgather, dist_mode::halo, dist_mode::rounds})
             for (const bool overlap : {true, false}) {
-                const int before = g_failures;
-                std::string transport;
-                const auto dist = run_dist(P, A, sizes, X, Y, fused, mode, overlap, &transport, single);
-                compare(P, dist, single, (double)n);
-                const char *mn = mode == dist_mode::allgather ? "allgather" : mode == dist_mode::halo ? "halo" : "rounds";
-                std::printf("%s: dist_gcn P=%zu %s overlap=%d fused=%d transport=%s  loss %.7f -> %.7f (single GPU %.7f -> %.7f)\n",
-                            g_failures == before ? "TEST PASSED" : "TEST FAILED", P, mn, (int)overlap, (int)fused, transport.c_str(),
-                            dist.loss[0], dist.loss[1], single.loss[0], single.loss[1]);
+                epoch_result by_threads[2];
+                for (const int threads : {1, 0}) {         // one enqueue thread per GPU / the calling thread does it all
+                    const int before = g_failures;
+                    setenv("MGGCN_ENQUEUE_THREADS", threads ? "1" : "0", 1);
+                    std::string transport;
+                    const auto dist = run_dist(P, A, sizes, X, Y, fused, mode, overlap, &transport, single);
+                    compare(P, dist, single, (double)n);
+                    by_threads[threads] = dist;
+                    if (!threads) CHECK(same_bits(by_threads[0], by_threads[1]));
+                    const char *mn = mode == dist_mode::allgather ? "allgather" : mode == dist_mode::halo ? "halo" : "rounds";
+                    std::printf("%s: dist_gcn P=%zu %s overlap=%d fused=%d threads=%d transport=%s  loss %.7f -> %.7f (single GPU %.7f -> %.7f)\n",
+                                g_failures == before ? "TEST PASSED" : "TEST FAILED", P, mn, (int)overlap, (int)fused, threads, transport.c_str(),
+                                dist.loss[0], dist.loss[1], single.loss[0], single.loss[1]);
+                }
             }
     }
+    unsetenv("MGGCN_ENQUEUE_THREADS");
+    if (P >= 3)
+        for (const int threads : {1, 0}) {
+            setenv("MGGCN_ENQUEUE_THREADS", threads ? "1" : "0", 1);
+            test_late_rank(P);
+        }
+    unsetenv("MGGCN_ENQUEUE_THREADS");
     // halo volume matrix of the partition (the figure test/data/prep.py:237-244 prints)
     if (P > 1) {
         dist_context ctx(P);

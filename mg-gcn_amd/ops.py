@@ -103,8 +103,13 @@ def prebuild_plans(ctx: context, wants, max_parallel: int = 4) -> None:
         return ctx.lib.mggcn_spmm_plan_create_for(A.n(), A.m(), A.indptr.ctypes.data, A.indices.ctypes.data,
                                                   A.data.ctypes.data, max_d, d_hint)
     todo = list(jobs.values())
-    with ThreadPoolExecutor(max_workers=max(1, min(max_parallel, len(todo)))) as pool:
-        handles = list(pool.map(build, todo))
+    workers = max(1, min(max_parallel, len(todo)))
+    ctx.lib.mggcn_spmm_plan_concurrent_builders(workers)        # every builder threads over its share of the cores
+    try:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            handles = list(pool.map(build, todo))
+    finally:
+        ctx.lib.mggcn_spmm_plan_concurrent_builders(1)
     for (A, max_d, d_hint, key), h in zip(todo, handles):
         buf = A.__dict__["_spmm_plans"][key] = spmm_buffer(ctx.lib, h)
         buf.max_d, buf.d_hint, buf.version = max_d, d_hint, A._version

@@ -40,14 +40,20 @@ def test_bench_single_gpu_prints_one_json_line():
     assert out["hoisted_first_aggregation"]["epoch_ms"] > 0 and out["hoisted_first_aggregation"]["spmm_per_epoch"] == 6
 
 
+def _rehearsal(args, port_env=None):
+    """plain `python bench.py --gpus 2 ...` -- NO launcher: bench.py starts its ranks itself"""
+    env = dict(os.environ, MGGCN_BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY", "MGGCN_HOST_THREADS"):
+        env.pop(k, None)                                # bench.py must set what its ranks need by itself
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05"] + args,
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return _one_json_line(r.stdout)
+
+
 @pytest.mark.gpu
 def test_bench_multi_rank_rehearsal_prints_one_json_line():
-    env = dict(os.environ, MGGCN_BENCH_REHEARSAL="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    out = _one_json_line(r.stdout)
+    out = _rehearsal([])
     assert REQUIRED <= set(out)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["parallelism"].startswith("rows2")
     assert out["loss_first_last"][1] < out["loss_first_last"][0]
@@ -57,6 +63,21 @@ def test_bench_multi_rank_rehearsal_prints_one_json_line():
     assert [d["rank"] for d in comm["devices"]] == [0, 1] and all("name" in d and "device" in d for d in comm["devices"])
     assert comm["mode"] == "allgather" and comm["overlap"] is True and "rccl_version" in comm
     assert comm["exchange_ms"] > 0 and comm["exposed_ms"] >= 0 and comm["overlap_frac"] is not None
+    # the PRODUCT path next to it: `mg_gcn -P 2 -R 1 train <the same files>` after the ranks have let go of the GPU
+    # (two ranks wrapped over this box's one GPU: peer-copy transport, one enqueue thread per rank)
+    assert out["cli_epoch_ms"] > 0 and out["cli_epochs"] == 8 and out["cli_setup_s"] >= 0
+    assert out["cli_transport"] == "p2p" and out["cli_enqueue_threads"] == 1
+    # same data, same seed-99 parameters, same padded class count: the two forms start at the same loss
+    assert abs(out["cli_loss_first"] - out["loss_first_last"][0]) <= 1e-4 * out["loss_first_last"][0]
+
+
+@pytest.mark.gpu
+def test_bench_rehearsal_schedules_are_within_2x_of_each_other():
+    """with a one-epoch warm-up the three exchange schedules must already be in steady state -- the round-3
+    rehearsals showed the all-gather schedule at 4x the others (gloo's list-form all_gather, not plan builds:
+    profiles/experiments/gloo_allgather_r04.log; fixed in dist.gloo_all_gather_rows)."""
+    ms = {mode: _rehearsal(["--mode", mode, "--no-extras"])["value"] for mode in ("allgather", "rounds", "halo")}
+    assert max(ms.values()) <= 2.0 * min(ms.values()), ms
 
 
 @pytest.mark.gpu
@@ -79,3 +100,8 @@ def test_bench_distributed_path_over_rccl_with_one_rank():
     assert comm["rccl_version"] and comm["devices"][0]["device"] == 0 and "gfx950" in comm["devices"][0]["arch"]
     assert comm["exchange_ms"] >= 0 and comm["exposed_ms"] >= 0
     assert out["loss_first_last"][1] < out["loss_first_last"][0]
+    # the CLI legs of the N > 1 line, here with the one rank: RCCL from the rank's enqueue thread, the peer-copy transport,
+    # and the reference's one-thread form -- all three at the Python form's first loss
+    for leg, transport, threads in (("cli", "rccl", 1), ("cli_p2p", "p2p", 1), ("cli_serial", "rccl", 0)):
+        assert out[f"{leg}_epoch_ms"] > 0 and out[f"{leg}_transport"] == transport and out[f"{leg}_enqueue_threads"] == threads, out
+        assert abs(out[f"{leg}_loss_first"] - out["loss_first_last"][0]) <= 1e-4 * out["loss_first_last"][0]

@@ -1,0 +1,20 @@
+"""The engine's host-only code under AddressSanitizer + UndefinedBehaviorSanitizer and under ThreadSanitizer, on the
+CPU: `make -C tests/native sanitize` builds tests/native/plan_host_test.cpp twice with plain g++ and
+runs both.  Under test: the SpMM plan builders' host passes (mg-gcn_amd/csrc/plan_host.cpp -- threaded; the packed entry
+streams are decoded and replayed as an SpMM against the oracle), the host preprocessing (mg-gcn_amd/csrc/host_prep.cpp
+-- threaded; bit-exact against the oracle) and the per-GPU command queues of the single-process host layer
+(mg-gcn_amd/host/enqueue.hpp).  GPU sanitizers do not exist on this pool; the device side is covered by the parity tests."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_code_is_clean_under_asan_ubsan_and_tsan():
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "native"), "sanitize"], capture_output=True, text=True,
+                       timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert out.count("ALL PASSED") == 2, out[-4000:]                  # once per sanitizer build
+    assert "TEST FAILED" not in out and "ERROR: AddressSanitizer" not in out and "WARNING: ThreadSanitizer" not in out
+    assert "runtime error" not in out                                # UndefinedBehaviorSanitizer
