@@ -59,7 +59,7 @@ def spmm_kernel_sha():
     collected with, so a stale `traffic` figure is visible in the line (and fails tests/test_abi_host.py)"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("spmm.hip", "spmm_sweep.hip", "spmm_internal.h"):
+    for f in ("spmm.hip", "spmm_sweep.hip", "spmm_internal.h", "plan_host.cpp", "plan_host.h"):
         with open(os.path.join(ROOT, "mg-gcn_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -94,19 +94,23 @@ def cli_leg(dataset_dir, cwd, hidden, flags=(), env=None, epochs=8, timeout=300)
     wall = time.perf_counter() - t
     if proc.returncode != 0:
         return {"error": err[-300:]}
-    ep, info = [], {}
+    ep, info, issue = [], {}, []
     for ln in err.splitlines():
         t4 = ln.split()
         if len(t4) == 4 and t4[0].isdigit():
             ep.append((float(t4[1]), float(t4[3])))
         elif ln.startswith("[mggcn timing] transport ") and len(t4) >= 6:
             info = {"transport": t4[3], "enqueue_threads": int(t4[5])}
+        elif ln.startswith("[mggcn timing] epoch ") and len(t4) == 6 and t4[4] == "host-issue-ms":   # wall time minus the wait for the devices
+            issue.append(float(t4[5]))
     if len(ep) < 3:
         return {"error": "no epoch lines"}
     med = float(np.median([x[1] for x in ep[2:]]))
     out = {"epoch_ms": round(med * 1e3, 4), "setup_s": round(wall - sum(x[1] for x in ep[1:]) - med, 2),
            "loss_first": ep[0][0], "epochs": len(ep)}
     out.update(info)
+    if len(issue) >= 3:
+        out["host_issue_ms"] = round(float(np.median(issue[2:])), 4)
     return out
 
 
@@ -246,10 +250,22 @@ def main():
         if P == 1 and "RANK" not in os.environ:                 # forced single-rank run without a launcher
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
                               MASTER_PORT=os.environ.get("MASTER_PORT", "29571"))
+        high_priority_comm = False
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # RCCL's kernels on a HIGH-priority stream, like the reference's communication stream (stream_create(i, 0),
+            # src/matrix.hpp:53-60, :82): ProcessGroupNCCL runs its collectives on an internal stream of its own -- the
+            # context's comm stream only carries the event edges -- and that stream is of default priority unless asked
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+            except Exception:                                   # noqa: BLE001 -- an older torch: default priority
+                opts = None
+            kw = {"pg_options": opts} if opts is not None else {}
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
+            high_priority_comm = opts is not None
 
     # ---- workload ------------------------------------------------------------------
     t_gen = time.time()
@@ -407,6 +423,7 @@ def main():
 
     if multi:
         out["comm"] = comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers, args)
+        out["comm"]["high_priority_stream"] = high_priority_comm
     if rank == 0 and not multi and not args.no_extras:
         # (1) the reference's own interface on the same workload: never the headline (it synchronises inside the loss
         #     like the reference, src/gcn.hpp:816; `value` goes through gcn.train_step with one sync per epoch)
@@ -504,22 +521,25 @@ def comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers,
            "mode": args.mode, "overlap": not args.no_overlap, "rehearsal_gloo_on_one_gpu": bool(rehearsal),
            "chunks": int(os.environ.get("MGGCN_DIST_CHUNKS", "0")) or None}
     ex, wt = [], []
-    try:                                  # the headline is already measured: a failure here must not cost the line
-        dctx.profile_exchange = True
-        for it in range(3):
-            epoch()
-            if it == 0:
-                continue                                          # first pass creates the events
+    # The epochs themselves run OUTSIDE any try: they are collectives, and a rank that swallowed an error in the middle of one
+    # would leave its peers blocked in it -- an error there ends the run, like in the timed epochs.  Only the
+    # rank-local read-out of the event timers is guarded: a failure there costs the comm figures, not the line.
+    dctx.profile_exchange = True
+    for it in range(3):
+        epoch()
+        if it == 0 or "exchange_error" in rep:
+            continue                                              # first pass creates the events; after a read-out failure the
+                                                                  # epochs still run (every rank makes the same collective calls)
+        try:
             for t in spmm_timers:                                 # "<layer>_<0|1>_matmul-spmm"
                 base = t[: -len("matmul-spmm")]
                 names = [k for k in dctx.ctx.timers if k.startswith(base)]
                 ex.append(sum(dctx.measure(k) for k in names if k.endswith("matmul-exchange")))
                 wt.append(sum(dctx.measure(k) for k in names if k.endswith("matmul-bcast-wait")))
-    except Exception as e:                # noqa: BLE001 -- reported in the line
-        rep["exchange_error"] = repr(e)[:200]
-        ex = []
-    finally:
-        dctx.profile_exchange = False
+        except Exception as e:            # noqa: BLE001 -- reported in the line
+            rep["exchange_error"] = repr(e)[:200]
+            ex = []
+    dctx.profile_exchange = False
     # every rank takes part in this reduction whatever happened above (a rank whose pass failed is seen by the MIN reduction below)
     e, w = (float(np.mean(ex)), float(np.mean(wt))) if ex else (0.0, 0.0)
     both = torch.tensor([e, w], dtype=torch.float64, device="cpu" if rehearsal else "cuda")

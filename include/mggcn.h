@@ -135,6 +135,11 @@ void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan);
  * its own passes over cores / n instead of all the cores (MGGCN_HOST_THREADS in the environment still wins).  Set it back
  * to 1 afterwards.  Process-wide. */
 void mggcn_spmm_plan_concurrent_builders(uint32_t n);
+/* Plans built from now on size their launch rounds to leave n compute units' worth of wave slots free: for SpMMs that run
+ * while a collective kernel (RCCL) shares the device -- a round of exactly the resident set would end in a second, nearly
+ * empty pass for the workgroups the foreign kernel displaced (+57 % measured).  The distributed host
+ * layers set 16 around their plan builds and 0 afterwards; MGGCN_SPMM_RESERVED_CUS in the environment overrides.  Process-wide. */
+void mggcn_spmm_plan_reserved_cus(uint32_t n);
 /* introspection (tests, DESIGN.md figures) */
 uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan);
 uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan);
@@ -149,6 +154,10 @@ uint32_t mggcn_spmm_plan_num_slices(const mggcn_spmm_plan *plan);      /* column
  * prints the same line to stderr whenever a plan is created.  The tuning knobs (MGGCN_SPMM_*) are read once, here,
  * never on the launch path. */
 int mggcn_spmm_plan_describe(const mggcn_spmm_plan *plan, char *out, size_t cap);
+/* diagnostics (experiments only): n_blocks workgroups of 256 threads that hold their wave slots until *stop_flag (device memory, or mapped
+ * pinned host memory) is non-zero or max_microseconds have passed -- a stand-in for the channels of a collective
+ * kernel sharing the device with the SpMM (profiles/experiments/coresident_r04.py). */
+void mggcn_debug_occupy_cus(mggcn_stream_t stream, uint32_t n_blocks, uint32_t max_microseconds, const uint32_t *stop_flag);
 /* diagnostics: with MGGCN_SPMM_STAMPS=1 in the environment at plan creation the d >= 96 sweep kernel records, per
  * one-wave task of column slice `slice`, {start, end} on the 100 MHz constant clock and {HW_ID << 32 | blockIdx << 4 | XCC id} of
  * its LAST launch; this copies them out (3 x u64 per task, blocking) and returns the task count.  Never set in a

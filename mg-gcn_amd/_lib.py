@@ -51,6 +51,8 @@ PROTOTYPES = {
     "mggcn_spmm_plan_create_for": (vp, [c_uint32, c_uint32, vp, vp, vp, c_uint32, c_uint32]),
     "mggcn_spmm_plan_destroy": (None, [vp]),
     "mggcn_spmm_plan_concurrent_builders": (None, [c_uint32]),
+    "mggcn_spmm_plan_reserved_cus": (None, [c_uint32]),
+    "mggcn_debug_occupy_cus": (None, [vp, c_uint32, c_uint32, vp]),
     "mggcn_spmm_plan_num_items": (c_uint32, [vp]),
     "mggcn_spmm_plan_num_split_rows": (c_uint32, [vp]),
     "mggcn_spmm_plan_num_sweep_tasks": (c_uint32, [vp]),

@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include <map>
+#include <vector>
 #include <type_traits>
 #include <mutex>
 #include <utility>
@@ -665,20 +666,25 @@ MGGCN_API void mggcn_scale_mat_f32(mggcn_stream_t stream, float *mat, float scal
 // a host layer whose streams come from elsewhere (torch) calls this when it drops a stream, so that a recycled
 // stream handle never inherits a buffer another stream may still be using, and nothing accumulates.
 MGGCN_API void mggcn_stream_release_scratch(mggcn_stream_t stream) {
-    int dev = 0;
-    MGGCN_CHECK_HIP(hipGetDevice(&dev));
-    float *p = nullptr;
+    // by STREAM alone, whatever device is current on the calling thread (a stream handle belongs to one device; a context
+    // may be dropped from a thread that has another device current -- the entry must still be found, or a recycled handle
+    // inherits the buffer)
+    std::vector<std::pair<int, float *>> mine;
     {
         std::lock_guard<std::mutex> lock(g_scratch_mu);
-        auto it = g_scratch.find({dev, as_stream(stream)});
-        if (it == g_scratch.end()) return;
-        p = it->second;
-        g_scratch.erase(it);
+        for (auto it = g_scratch.begin(); it != g_scratch.end();)
+            if (it->first.second == as_stream(stream)) { mine.push_back({it->first.first, it->second}); it = g_scratch.erase(it); }
+            else ++it;
     }
-    if (p) {
+    if (mine.empty()) return;
+    int prev = 0;
+    MGGCN_CHECK_HIP(hipGetDevice(&prev));
+    for (const auto &m : mine) {
+        MGGCN_CHECK_HIP(hipSetDevice(m.first));
         MGGCN_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));      // nobody may still be summing into it
-        MGGCN_CHECK_HIP(hipFree(p));
+        MGGCN_CHECK_HIP(hipFree(m.second));
     }
+    MGGCN_CHECK_HIP(hipSetDevice(prev));
 }
 
 MGGCN_API void mggcn_abssum_f32(mggcn_stream_t stream, const float *A, size_t size, float *result_device) {

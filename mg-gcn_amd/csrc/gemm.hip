@@ -574,8 +574,9 @@ Split choose_split(uint32_t M, uint32_t N, uint32_t K) {
         splits = std::min<uint32_t>(want, k_steps / 8);   // at least 8 K-steps per slice
         splits = std::max<uint32_t>(splits, 1u);
     }
-    if (const char *e = std::getenv("MGGCN_GEMM_SPLITS"))          // tuning knob (profiles/experiments/gemm_splits.py)
-        splits = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)std::strtoul(e, nullptr, 10), k_steps));
+    // tuning knob (profiles/experiments/gemm_splits.py), read ONCE: this runs on every GEMM dispatch and workspace query
+    static const uint32_t forced = [] { const char *e = std::getenv("MGGCN_GEMM_SPLITS"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 0u; }();
+    if (forced) splits = std::max<uint32_t>(1u, std::min<uint32_t>(forced, k_steps));
     const uint32_t steps_per = (k_steps + splits - 1) / splits;
     splits = (k_steps + steps_per - 1) / steps_per;
     return {splits ? splits : 1u, steps_per * BK};

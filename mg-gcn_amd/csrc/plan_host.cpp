@@ -25,6 +25,7 @@ void require(bool ok, const char *what) {
 }
 
 std::atomic<unsigned> g_concurrent_builders{1};
+std::atomic<unsigned> g_reserved_cus{0};
 
 // matrices below this many non-zeros are handled by the calling thread alone (MGGCN_HOST_THREADS_MIN_NNZ: tests)
 uint64_t thread_threshold(uint64_t dflt) {
@@ -67,6 +68,8 @@ uint32_t env_u32(const char *name, uint32_t dflt) {
     if (!s || !*s) return dflt;
     return (uint32_t)std::strtoul(s, nullptr, 10);
 }
+
+void set_reserved_cus(unsigned n) { g_reserved_cus.store(n, std::memory_order_relaxed); }
 
 void set_concurrent_builders(unsigned n) { g_concurrent_builders.store(std::max(1u, n), std::memory_order_relaxed); }
 
@@ -261,7 +264,15 @@ bool sweep_build_host(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr, 
     // 64 MiB slices: 2.69 ms (3 blocks/CU 3.11, 5 -> 3.56; the float4 kernels hold 128 VGPRs, so
     // four blocks of four waves is also what fits).
     const uint32_t blocks_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u), 8u));
-    const uint32_t round_tasks = num_cu * blocks_per_cu * kWavesPerBlock;
+    // Compute units' worth of wave slots a launch round leaves free for a kernel that SHARES the device with the SpMM -- the
+    // channels of a collective (RCCL) kernel: every workgroup of it that sits on a CU displaces one of the four SpMM workgroups
+    // there, and a round of EXACTLY the resident set then ends in a second, nearly empty pass.  Measured with a stand-in
+    // (profiles/experiments/coresident_r04.log; rank 0's share of the Reddit shape at P = 2, two full rounds per SpMM): 1.29 ms
+    // alone, 2.01 ms next to as few as 16 foreign workgroups; with 16 CUs reserved 1.32 ms alone and 1.25-1.27 ms next to 16-64
+    // of them.  Set per plan build by the distributed host layers (mggcn_spmm_plan_reserved_cus), MGGCN_SPMM_RESERVED_CUS
+    // overrides; 0 = the device is ours (every single-GPU plan).
+    const uint32_t reserved = std::min(env_u32("MGGCN_SPMM_RESERVED_CUS", g_reserved_cus.load(std::memory_order_relaxed)), num_cu - 1u);
+    const uint32_t round_tasks = (num_cu - reserved) * blocks_per_cu * kWavesPerBlock;
 
     // (MGGCN_SPMM_SWEEP_ROWS_PER_TASK caps it for experiments: 8 rows per wave -- twice the launches,
     //  same slices -- ran 2.88 ms against 2.69 at 16, 4 rows 3.00: profiles/experiments/sweep_rows_per_task_r01.log)

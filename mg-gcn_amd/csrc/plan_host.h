@@ -3,7 +3,7 @@
 // mggcn_spmm_plan_create_for (spmm.hip) = these passes + device allocation and upload.  They live in
 // their own translation unit (plan_host.cpp) so that the same code can be compiled with plain g++
 // under AddressSanitizer / UndefinedBehaviorSanitizer / ThreadSanitizer and driven on the CPU
-// (csrc/tests/plan_host_test.cpp, `make sanitize`, tests/test_sanitizers.py): the passes are threaded
+// (tests/native/plan_host_test.cpp, `make -C tests/native sanitize`, tests/test_sanitizers.py): the passes are threaded
 // (per-thread counters, per-row offsets, one task range per thread) and build the packed entry
 // streams every sweep kernel trusts blindly.  Not part of the ABI.
 //
@@ -127,5 +127,7 @@ uint32_t env_u32(const char *name, uint32_t dflt);
 // running side by side (set_concurrent_builders; csr_matrix::prebuild_plans runs up to four), capped at `cap`
 unsigned host_threads(unsigned cap);
 void set_concurrent_builders(unsigned n);
+// compute units' worth of wave slots the launch rounds of plans built FROM NOW ON leave free (see sweep_build_host)
+void set_reserved_cus(unsigned n);
 
 }  // namespace mggcn_plan

@@ -111,7 +111,29 @@ namespace {
 __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t *__restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
 }
+
+__global__ __launch_bounds__(256) void occupy_kernel(const volatile uint32_t *stop, unsigned long long max_ticks) {
+    // one wave slot per SIMD of whatever CU the block lands on, like a communication kernel's channel; leaves when told to
+    // or when the time is up (100 MHz constant clock): every wave reaches one of the two
+    // (the flag is looked at every ~50 us: sixty-four waves polling a host-memory word back to back delay every packet the
+    // command processor fetches over the same path -- the first version of this stand-in slowed the LAUNCHES it was meant to
+    // share the device with by 20 us per workgroup of its own)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < max_ticks) {
+        for (int k = 0; k < 16; k++) __builtin_amdgcn_s_sleep(127);
+        if (*stop) break;
+    }
+}
 }  // namespace
+
+// Diagnostics (profiles/experiments/coresident_r04.py, never on the product path): n_blocks workgroups of 256 threads that
+// do nothing but hold their wave slots until *stop_flag (device memory, or mapped pinned host memory) becomes non-zero or
+// max_microseconds have passed -- a stand-in for the channels of a collective kernel that shares the device with the SpMM.
+MGGCN_API void mggcn_debug_occupy_cus(mggcn_stream_t stream, uint32_t n_blocks, uint32_t max_microseconds, const uint32_t *stop_flag) {
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(occupy_kernel, dim3(n_blocks), dim3(256), 0, as_stream(stream), stop_flag, (unsigned long long)max_microseconds * 100ull);
+    MGGCN_CHECK_LAUNCH();
+}
 
 // Small word-aligned ranges (the loss layer's two scalars, a bias gradient) are zeroed by a kernel of this library, not by
 // hipMemsetAsync: the runtime's fill path put a ~100 us bubble between its blit kernel and the next kernel of the stream

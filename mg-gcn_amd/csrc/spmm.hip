@@ -460,6 +460,7 @@ MGGCN_API void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan) {
 }
 
 MGGCN_API void mggcn_spmm_plan_concurrent_builders(uint32_t n) { mggcn_plan::set_concurrent_builders(n); }
+MGGCN_API void mggcn_spmm_plan_reserved_cus(uint32_t n) { mggcn_plan::set_reserved_cus(n); }
 
 MGGCN_API uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan) { return plan->n_items; }
 MGGCN_API uint32_t mggcn_spmm_plan_num_split_rows(const mggcn_spmm_plan *plan) { return plan->n_split_rows; }

@@ -36,6 +36,8 @@ src/cuda_utils.hpp:61-89).  Two modes:
 """
 from __future__ import annotations
 
+import os
+
 import ctypes
 from typing import List, Optional, Sequence, Tuple
 
@@ -297,6 +299,9 @@ class dist_context(host_comm):
         # bench.py's exchange pass: extra events around every exchange (comm-stream time of the collectives, time the
         # compute stream spends waiting for each piece).  Off in timed epochs: ~10 more event records per SpMM.
         self.profile_exchange = False
+        # MGGCN_DIST_SELF_GATHER=1 (tests of the transport): run the all-gather with ONE rank too -- the only way to put
+        # ProcessGroupNCCL's all_gather_into_tensor on a one-GPU box; by default a single rank exchanges nothing
+        self.self_gather = os.environ.get("MGGCN_DIST_SELF_GATHER", "0") == "1"
         if device_index is None:
             device_index = self.rank % max(_lib.require_gpu(), 1)
         self.ctx = context(device_index)
@@ -588,17 +593,29 @@ class dist_sparse_linear:
         self.plans = {}
         self._views = {}
         self._halo_send = None
+        self._shared_device = False          # set on first use: more than one rank and overlap on
 
     def _plan(self, ctx: context, key, M: csr_matrix, d: int):
         pl = self.plans.get(key)
         if pl is None:
-            pl = self.plans[key] = ops.spmm_plan_for(ctx, M, max(d, 128), d)     # shared across layers
+            # with more than one rank these SpMMs run while RCCL's kernels share the device: their launch rounds leave 16
+            # CUs' worth of wave slots free (include/mggcn.h: mggcn_spmm_plan_reserved_cus; +57 % per SpMM without, measured
+            # with a stand-in: profiles/experiments/coresident_r04.log)
+            shared = self._shared_device
+            if shared:
+                ctx.lib.mggcn_spmm_plan_reserved_cus(16)
+            try:
+                pl = self.plans[key] = ops.spmm_plan_for(ctx, M, max(d, 128), d)     # shared across layers
+            finally:
+                if shared:
+                    ctx.lib.mggcn_spmm_plan_reserved_cus(0)
         return pl
 
     def _run(self, dctx: dist_context, A: dist_row_csr_matrix, tag: str, B: dist_row_dn_matrix,
              C: dist_row_dn_matrix, discard: bool, flags: int) -> None:
         torch = _torch()
         ctx, P, r = dctx.ctx, dctx.P, dctx.rank
+        self._shared_device = P > 1 and dctx.overlap
         name = self.name + tag
         beta = 0.0 if discard else 1.0
         d = B.m()
@@ -622,8 +639,11 @@ class dist_sparse_linear:
             for c in range(K):
                 g, piece = views[c]
                 gathered.append(g)
-                pend.append(dctx.all_gather_rows(piece, g.t, cs))
-            prof = dctx.profile_exchange
+                # one rank: nothing is remote, nobody reads the gathered copy -- and the "all-gather" would be a 119 MB
+                # copy kernel sharing the device with the local SpMM (profiles/r04_forced_dist_summary.md: the sweep
+                # round that meets it takes 500-700 us instead of 300)
+                pend.append(dctx.all_gather_rows(piece, g.t, cs) if (P > 1 or dctx.self_gather) else None)
+            prof = dctx.profile_exchange and (P > 1 or dctx.self_gather)
             if prof:                                           # comm-stream time of the whole exchange
                 for c in range(K):
                     pend[c].wait(cs)
@@ -638,7 +658,8 @@ class dist_sparse_linear:
                     ctx.record(name + f"{c}_matmul-bcast-ready", 0)
                     ctx.register_timer(name + f"{c}_matmul-bcast-wait", name + f"{c}_matmul-bcast-ready",
                                        name + f"{c}_matmul-bcast-finish")
-                pend[c].wait(0)                                # also at P == 1: the buffer is reused by the next call
+                if pend[c] is not None:
+                    pend[c].wait(0)
                 ctx.record(name + f"{c}_matmul-bcast-finish", 0)
                 if P > 1:
                     blk = A.remote_chunks[c]

@@ -212,7 +212,10 @@ class gcn_layer:
             # SpMM at d = in, kept: n x in floats) and the epoch runs one SpMM fewer.  Not what the reference executes
             # per epoch (src/gcn.hpp:437-446): an option, off by default, reported separately by bench.py.  The
             # backward pass is the reference's (G_W = X^T T with the first layer's backward SpMM skipped, :954).
-            key = (H.buffer(), H.n(), H.m())
+            # keyed on the feature buffer AND the matrix's generation (csr_matrix bumps _version when it is re-normalised
+            # or replaced).  An IN-PLACE update of the feature tensor is not visible here: call
+            # set_hoist_first_aggregation(True) again (it drops the cached product) after changing X in place.
+            key = (H.buffer(), H.n(), H.m(), getattr(self.A.A, "_version", 0))
             if self._AX is None or self._AX_key != key:
                 self._AX = dn_matrix(self.A.A.n(), H.m())
                 self.A(ctx, H, self._AX)
@@ -450,9 +453,13 @@ class gcn:
         feature matrix is passed every epoch (full-graph training does) and only for a GEMM-first first layer without a
         residual branch; 6 instead of 7 SpMMs per epoch on the Reddit model.  Off = the reference's epoch."""
         l0 = self.layers_[0]
-        l0.hoist_input = bool(on) and l0.gemm_first() and not l0.residual_layer
-        if not on:
-            l0._AX = l0._AX_key = None
+        # A_fwd (1 b^T) = 1 b^T needs EVERY row of A_fwd to sum to one: a vertex without a single entry in its row of
+        # A_fwd (no self-loop, nobody points at it) has row sum 0 and would get 0 instead of b -- the reference's data-prep
+        # adds self-loops (test/data/prep.py:113), but the engine does not assume it: such a graph keeps the plain path
+        fwd = l0.A.A
+        stochastic = bool(np.all(np.diff(fwd.indptr.astype(np.int64)) > 0)) if fwd.n() else True
+        l0.hoist_input = bool(on) and l0.gemm_first() and not l0.residual_layer and stochastic
+        l0._AX = l0._AX_key = None                  # (re-)enabling recomputes the product: the way to pick up an in-place change of X
 
     def __call__(self, ctx: context, H: dn_matrix) -> dn_matrix:
         if self._plan_wants:                          # first call: the context (device) is known now

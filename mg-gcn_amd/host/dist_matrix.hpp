@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cstdlib>
 #include <numeric>
 #include <ostream>
@@ -28,9 +29,15 @@ class dist_context {
     // one enqueue thread per GPU (enqueue.hpp); null: the calling thread issues everything itself, GPU after GPU,
     // like the reference (src/cuda_utils.hpp:57-92).  Shared by the copies of a context (contexts are passed by value).
     std::shared_ptr<mggcn::enqueue_pool> pool_;
+    // host seconds sync() has spent waiting for the DEVICES (after every command had been issued): an epoch's wall time
+    // minus this is what the host needed to issue it -- the figure that says whether the process is host-bound
+    std::shared_ptr<double> device_wait_s_ = std::make_shared<double>(0.0);
 
 public:
     bool overlap = true;
+    // MGGCN_DIST_SELF_GATHER=1 (tests of the transport): the all-gather schedule exchanges with ONE rank too (RCCL's
+    // single-rank all-gather); by default one rank exchanges nothing
+    bool self_gather = false;
 
     int bcast_stream_id() const { return overlap ? 1 : 0; }     // reference :20-22
 
@@ -51,6 +58,7 @@ public:
         // the host layer releases its send buffers itself, on the compute stream at the end of an SpMM (ops.hpp), and
         // its remote blocks never read a rank's own piece of the gathered matrix
         mggcn_comm_set_exchange_flags(comm_.get(), MGGCN_COMM_DEFER_RELEASE | MGGCN_COMM_SKIP_SELF);
+        if (const char *sg = std::getenv("MGGCN_DIST_SELF_GATHER")) self_gather = std::atoi(sg) != 0;
         const char *et = std::getenv("MGGCN_ENQUEUE_THREADS");
         if (et ? std::atoi(et) != 0 : P > 1)
             pool_ = std::make_shared<mggcn::enqueue_pool>(P, [devices](std::size_t j) { mggcn_set_device(devices[j]); });
@@ -72,7 +80,13 @@ public:
     }
     // every command pushed so far has been issued; rethrows what a command threw
     void drain() const { if (pool_) pool_->drain(); }
-    void sync() const { drain(); for (const auto &c : contexts) c.sync(); }
+    void sync() const {
+        drain();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (const auto &c : contexts) c.sync();
+        *device_wait_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    double device_wait_seconds() const { return *device_wait_s_; }
 
     std::vector<mggcn_stream_t> streams(std::size_t stream_id) const {
         std::vector<mggcn_stream_t> s;

@@ -30,6 +30,7 @@ class sparse_linear {
 
 public:
     sparse_linear(std::string name, csr_t A, csr_t A_T) : name(name), A(A), A_T(A_T) {}
+    const csr_t &forward_matrix() const { return A; }
 
     void operator()(context ctx, dn_t B, dn_t C, bool discard = true, uint32_t flags = 0) {
         if (!ext_buffer) ext_buffer = get_matmul_buffer(ctx, A, B, C);      // plan is width-independent up to 128+
@@ -351,9 +352,17 @@ class gcn_layer {
     bool hoist_input = false;
     dn_matrix<r_t> AX;
     const r_t *AX_src = nullptr;
+    unsigned AX_generation = 0;
 
 public:
-    void set_hoist_input(bool on) { hoist_input = on && gemm_first() && !residual_layer; if (!on) { AX = dn_matrix<r_t>(); AX_src = nullptr; } }
+    // A_fwd (1 b^T) = 1 b^T needs every row of A_fwd to sum to one: a vertex whose row of A_fwd is empty (no self-loop, nobody
+    // points at it) would get 0 instead of b -- such a graph keeps the plain path.  (Re-)enabling drops the cached product:
+    // the way to pick up an in-place change of the feature matrix, which the (buffer, shape, matrix generation) key cannot see.
+    void set_hoist_input(bool on) {
+        hoist_input = on && gemm_first() && !residual_layer && A.forward_matrix().every_row_nonempty();
+        AX = dn_matrix<r_t>();
+        AX_src = nullptr;
+    }
     bool hoists_input() const { return hoist_input; }
     bool gemm_first() const { return HW.m() == AHW.m(); }           // out <= in (reference :439)
     bool has_activation() const { return activation; }
@@ -386,10 +395,11 @@ public:
             // layer 0's aggregation is loop-invariant: A_fwd (X W + 1 b^T) = (A_fwd X) W + 1 b^T (A_fwd is row-stochastic,
             // X never changes between epochs): A_fwd X once, one SpMM fewer per epoch.  NOT the reference's epoch
             // (:437-446): an option, off by default.  The backward pass stays the reference's (G_W = X^T T, :954).
-            if (!AX.buffer() || AX_src != H.buffer() || AX.n() != AHW.n() || AX.m() != H.m()) {
+            if (!AX.buffer() || AX_src != H.buffer() || AX.n() != AHW.n() || AX.m() != H.m() || AX_generation != A.forward_matrix().generation()) {
                 AX = dn_matrix<r_t>(AHW.n(), H.m());
                 A(ctx, H, AX);
                 AX_src = H.buffer();
+                AX_generation = A.forward_matrix().generation();
             }
             lin(ctx, AX, AHW);
             lin.setX(H);

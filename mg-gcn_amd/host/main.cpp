@@ -193,12 +193,15 @@ int main_(int argc, char **argv) {
             ctx.record("training-start", 0);
             for (std::size_t e = 0; e < num_epochs; e++) {
                 const auto start = std::chrono::system_clock::now();
+                const double waited = ctx.device_wait_seconds();
                 auto [loss, acc] = G.train_forward(ctx, Xd, Yd);
                 G.backward(ctx);
                 G.adam_update(ctx, 1e-2, 0.9, 0.999, 5e-4, 1e-8);
                 ctx.sync();
                 const auto duration = std::chrono::duration<double>{std::chrono::system_clock::now() - start}.count();
                 std::cerr << e << ' ' << loss << ' ' << acc << ' ' << duration << "\n";
+                // how much of the epoch the host needed to ISSUE it (wall time minus the time it sat waiting for the devices)
+                if (stage.on) std::cerr << "[mggcn timing] epoch " << e << " host-issue-ms " << (duration - (ctx.device_wait_seconds() - waited)) * 1e3 << std::endl;
                 if (e == 0) stage("epoch 0 (exchange forms + SpMM plans built on first use)");
                 ctx.dump_timers(of, std::to_string(e) + "_");
             }

@@ -126,6 +126,7 @@ class csr_matrix {
         mggcn::device_ptr<v_t> d_indices;
         mggcn::device_ptr<r_t> d_data;
         int device = -1;
+        unsigned generation = 0;     // bumped whenever the values change (normalize): caches keyed on the matrix see it
         // SpMM plans built from this matrix, keyed (device, narrow lanes-per-row class | 0 = wide): the
         // layers of a model multiply by the same two matrices, so the plan (0.9 GB, ~1 s of host work at
         // the Reddit shape) is built once and shared (ops.hpp: get_matmul_buffer)
@@ -182,6 +183,12 @@ public:
     auto end(std::size_t i) const { return st_->indptr[i + 1]; }
     auto operator[](std::size_t i) const { return st_->indices[i]; }
     auto shape() const { return std::make_pair((std::size_t)st_->N, (std::size_t)st_->M); }
+    unsigned generation() const { return st_->generation; }
+    // every row holds at least one entry (a normalised adjacency with this property is row-stochastic)
+    bool every_row_nonempty() const {
+        for (v_t r = 0; r < st_->N; r++) if (st_->indptr[r + 1] == st_->indptr[r]) return false;
+        return true;
+    }
 
     // host arrays (the reference returns its managed pointers here, src/matrix.hpp:263-265)
     const std::vector<x_t> &indptr() const { return st_->indptr; }
@@ -210,6 +217,7 @@ public:
         mggcn_csr_normalize_host(st_->N, st_->M, st_->indptr.data(), st_->indices.data(), st_->data.data(), axis);
         st_->d_indptr.reset();
         st_->plans.clear();          // a sweep plan carries its own copy of the values
+        st_->generation++;
     }
 
     // plan of this matrix on the current device for feature width d (built on first use, shared by all

@@ -156,6 +156,13 @@ dist_spmm_buffers get_matmul_buffer(const dist_context ctx, const dist_row_csr_m
                         // enqueue thread may be using the same matrices meanwhile (first epoch only)
     out.block.resize(P);
     out.piece.resize(P);
+    // these SpMMs run while the exchange's kernels (RCCL channels, the peer-copy transport's sums) share the device: their launch
+    // rounds leave 16 CUs' worth of wave slots free (include/mggcn.h: mggcn_spmm_plan_reserved_cus)
+    struct reserve_scope {
+        bool on;
+        explicit reserve_scope(bool on) : on(on) { if (on) mggcn_spmm_plan_reserved_cus(16); }
+        ~reserve_scope() { if (on) mggcn_spmm_plan_reserved_cus(0); }
+    } reserve(P > 1 && ctx.overlap);
     {   // every rank's plans of this width, built side by side (csr_matrix::prebuild_plans), then picked up below
         std::vector<typename csr_matrix<x_t, v_t, r_t>::plan_want> wants;
         for (std::size_t j = 0; j < P; j++) {
@@ -222,7 +229,9 @@ void matmul_allgather(dist_context ctx, dist_row_csr_matrix<x_t, v_t, r_t> A, di
                                                           // previous call's readers of `gathered`)
     ctx.record(name + "0_matmul-bcast-start", cs);
     for (std::size_t c = 0; c < K; c++) {                 // all K pieces are queued at once and land in order
-        B.allgather(ctx, gathered, cb[c], cb[c + 1], cs);
+        // (one rank: nothing is remote and nobody reads the gathered copy -- the "all-gather" would be a copy kernel that shares
+        // the device with the local SpMM for nothing)
+        if (P > 1 || ctx.self_gather) B.allgather(ctx, gathered, cb[c], cb[c + 1], cs);
         ctx.record(name + std::to_string(c) + "_matmul-bcast-finish", cs);
     }
     for (std::size_t j = 0; j < P; j++)                   // local block: no dependency on the exchange

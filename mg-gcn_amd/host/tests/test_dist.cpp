@@ -253,6 +253,7 @@ int main(int argc, char **argv) {
     // profiles/experiments/time_dist_tests_r04.log: the suite runs as fast as with four; with 24 the driver time-slices
     // the queues and the same binary takes 50x as long).  Must be set before the first HIP call.
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    if (P == 1) setenv("MGGCN_DIST_SELF_GATHER", "1", 0);       // one rank: still put RCCL's all-gather through its paces
     const v_t n = argc > 2 ? (v_t)std::strtoull(argv[2], nullptr, 10) : 1536;      // 1536: divisible by 1, 2, 3, 4, 6, 8
     if (P == 0 || n % P != 0) { std::fprintf(stderr, "P must divide %u\n", n); return 2; }
     mggcn_set_device(0);

@@ -53,8 +53,9 @@ class context:
     def __del__(self):
         # the library keeps a small reduction scratch per (device, stream): hand it back with the streams, so that a
         # recycled stream handle never inherits it (torch owns the streams; the ABI's own streams do this on destroy)
+        # (looked up by stream alone: the thread's current device is left as it is -- this runs at garbage-collection
+        # time, possibly in the middle of another context's work on another device)
         try:
-            self.lib.mggcn_set_device(self.rank)
             for st in self.cuda_streams:
                 self.lib.mggcn_stream_release_scratch(st.cuda_stream)
         except Exception:

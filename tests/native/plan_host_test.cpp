@@ -147,7 +147,7 @@ static void check_sweep(const Csr &A, const uint32_t *ip, const uint32_t *ix, co
     if (!ok) return;
     const bool narrow = d_hint >= 1 && d_hint <= 64;
     CHECK(h.n_tasks == h.tasks.size() && h.task_rows.size() == (size_t)h.n_tasks * kRW && h.n_entries == h.entries.size());
-    CHECK(h.round_tasks == num_cu * env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u) * kWavesPerBlock);
+    CHECK(h.round_tasks == (num_cu - std::min(env_u32("MGGCN_SPMM_RESERVED_CUS", 0u), num_cu - 1u)) * env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u) * kWavesPerBlock);
     CHECK(((h.prio_bits_wide >> kNumCuPos) & kNumCuMask) == num_cu && ((h.prio_bits_narrow >> kNumCuPos) & kNumCuMask) == num_cu);
     CHECK(narrow ? (h.lpe == 4 || h.lpe == 8 || h.lpe == 12 || h.lpe == 16) && h.run_pad == 64 / h.lpe : h.lpe == 0 && h.run_pad == 2);
     const uint32_t G = h.run_pad;

@@ -40,6 +40,7 @@ def _worker(rank, P, port, n, F, C, hidden, mode, epochs, q, backend="gloo", chu
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if backend == "nccl":
         import torch
+        os.environ["MGGCN_DIST_SELF_GATHER"] = "1"          # one rank: the all-gather over ProcessGroupNCCL still runs
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=P, device_id=torch.device("cuda", 0))
     else:

@@ -87,7 +87,7 @@ def test_bench_distributed_path_over_rccl_with_one_rank():
     handles, the comm report (all_gather_object, RCCL version, the exchange-event pass) -- with the one rank a one-GPU
     box allows (MGGCN_BENCH_FORCE_DIST=1).  What it cannot show is a second rank; what it does show is that nothing on
     that path is gloo-only."""
-    env = dict(os.environ, MGGCN_BENCH_FORCE_DIST="1", MASTER_PORT="29549")
+    env = dict(os.environ, MGGCN_BENCH_FORCE_DIST="1", MASTER_PORT="29549", MGGCN_DIST_SELF_GATHER="1")   # one rank: exchange anyway
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--scale", "0.05"],
