@@ -77,6 +77,8 @@ def cli_leg(dataset_dir, cwd, hidden, flags=(), env=None, epochs=8, timeout=300)
     if not os.path.exists(exe):
         return None
     e = dict(os.environ)
+    if e.pop("MGGCN_HOST_THREADS_AUTO", None):        # the per-rank share of the cores was meant for N processes; this is one
+        e.pop("MGGCN_HOST_THREADS", None)
     e.update(env or {})
     e["MGGCN_TIMING"] = "1"
     cmd = [exe] + list(flags) + ["-E", str(epochs), "train", dataset_dir, str(len(hidden))] + [str(h) for h in hidden]
@@ -173,6 +175,7 @@ def multi_gpu_env(env, world):
         except AttributeError:
             avail = os.cpu_count() or 8
         env["MGGCN_HOST_THREADS"] = str(max(2, min(16, avail // (4 * max(world, 1)) or 2)))
+        env["MGGCN_HOST_THREADS_AUTO"] = "1"          # chosen here, not by the caller: the CLI legs (one process) drop it again
     return env
 
 
