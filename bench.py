@@ -151,7 +151,7 @@ def run_cli_multi_gpu(dataset_dir, P, hidden, mode, overlap, rehearsal, epochs=8
     out = {}
     try:
         for key, extra in legs:
-            r = cli_leg(dataset_dir, cwd, hidden, flags, dict(base, **extra), epochs=epochs, timeout=240)
+            r = cli_leg(dataset_dir, cwd, hidden, flags, dict(base, **extra), epochs=epochs, timeout=150)
             if r is None:
                 return None
             for k, v in r.items():
