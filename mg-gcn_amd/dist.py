@@ -1015,7 +1015,16 @@ class dist_gcn:
 
     def __call__(self, dctx, H):
         if self._plan_wants:
-            ops.prebuild_plans(dctx.ctx, self._plan_wants)
+            # with more than one rank these SpMMs run while RCCL's kernels share the device: launch rounds that leave 16 CUs'
+            # worth of wave slots free (include/mggcn.h: mggcn_spmm_plan_reserved_cus; profiles/r04_forced_dist_summary.md)
+            shared = dctx.P > 1 and dctx.overlap
+            if shared:
+                dctx.ctx.lib.mggcn_spmm_plan_reserved_cus(16)
+            try:
+                ops.prebuild_plans(dctx.ctx, self._plan_wants)
+            finally:
+                if shared:
+                    dctx.ctx.lib.mggcn_spmm_plan_reserved_cus(0)
             self._plan_wants = []
         for layer in self.layers_:
             H = layer(dctx, H)

@@ -635,3 +635,34 @@ def test_gemm_random_shapes_transposes_and_epilogues(pkg):
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     assert fuzz.run(cases=200, seed=2026) == 0
+
+
+def test_reserved_cus_shrink_the_launch_rounds_and_nothing_else(pkg, ctx, monkeypatch):
+    """mggcn_spmm_plan_reserved_cus(16): plans built under it size their launch rounds to (CUs - 16) x 16 one-wave tasks (SpMMs that
+    share the device with a collective kernel); the product is the same, and plans built afterwards are the
+    plain ones again.  80 000 rows = more than one round of 16-row tasks either way."""
+    import torch
+    n, d = 80_000, 128
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 3_000_000, 9000, seed=14)
+    A = pkg.csr_matrix(ip, ix, dv, n)
+    A.normalize(True)
+    B = np.random.default_rng(13).standard_normal((n, d), dtype=np.float32)
+    z = np.zeros((n, d), np.float32)
+    monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
+    monkeypatch.delenv("MGGCN_SPMM_RESERVED_CUS", raising=False)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    plain, bp = _run_spmm(pkg, ctx, A, B, z, 1.0, 0.0)
+    assert bp.num_sweep_tasks() > 0 and bp.num_sweep_tasks() % (cus * 16) == 0
+    ctx.lib.mggcn_spmm_plan_reserved_cus(16)
+    try:
+        A2 = pkg.csr_matrix(ip, ix, dv, n)                 # a fresh matrix: plans are cached per matrix
+        A2.normalize(True)
+        shared, bs = _run_spmm(pkg, ctx, A2, B, z, 1.0, 0.0)
+    finally:
+        ctx.lib.mggcn_spmm_plan_reserved_cus(0)
+    assert bs.num_sweep_tasks() % ((cus - 16) * 16) == 0 and bs.num_sweep_tasks() != bp.num_sweep_tasks()
+    assert rowwise_relerr(shared, plain) <= 2e-5
+    A3 = pkg.csr_matrix(ip, ix, dv, n)
+    A3.normalize(True)
+    _, b3 = _run_spmm(pkg, ctx, A3, B, z, 1.0, 0.0)
+    assert b3.num_sweep_tasks() == bp.num_sweep_tasks()
