@@ -454,7 +454,7 @@ def test_plan_follows_in_place_edits_of_the_matrix(pkg, oracle, ctx, monkeypatch
     must multiply with the edited matrix both through a fresh get_matmul_buffer and through the old handle."""
     monkeypatch.delenv("MGGCN_SPMM_ALGO", raising=False)
     n, d = 40_000, 128
-    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 3_000_000, 9000, seed=14)
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 8_000_000, 9000, seed=14)       # mean degree 100: dense enough for the sweep form
     dv = np.random.default_rng(14).random(dv.shape[0], dtype=np.float32) + 0.5
     A, Ao = _csr(pkg, oracle, ip, ix, dv.copy(), n)
     B = np.random.default_rng(15).standard_normal((n, d), dtype=np.float32)
@@ -643,7 +643,7 @@ def test_reserved_cus_shrink_the_launch_rounds_and_nothing_else(pkg, ctx, monkey
     plain ones again.  80 000 rows = more than one round of 16-row tasks either way."""
     import torch
     n, d = 80_000, 128
-    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 3_000_000, 9000, seed=14)
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, 8_000_000, 9000, seed=14)       # mean degree 100: dense enough for the sweep form
     A = pkg.csr_matrix(ip, ix, dv, n)
     A.normalize(True)
     B = np.random.default_rng(13).standard_normal((n, d), dtype=np.float32)
