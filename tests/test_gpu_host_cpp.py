@@ -103,6 +103,16 @@ def test_cpp_dist_classes_on_odd_shapes(shape):
     assert r.stdout.count("TEST PASSED") >= 12, r.stdout
 
 
+def test_cpp_dist_many_pieces_wrap_the_event_ring():
+    """40 pieces per SpMM and ONE release at its end: more exchanges in a row than the peer-copy transport has event slots per
+    rank (32) -- slots are re-used, ranks that are 16 exchanges behind with their releases release on the spot
+    (csrc/comm.cpp); every schedule still matches the single-GPU model at 1e-4, enqueue threads and one thread bit-identical."""
+    r = _run([os.path.join(BIN, "test_dist"), "4", "1536", "42", "24", "6", "32", "16"],
+             env={"MGGCN_OVERSUBSCRIBE": "1", "MGGCN_DIST_CHUNKS": "40"})
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "TEST FAILED" not in r.stdout and r.stdout.count("TEST PASSED") >= 12, r.stdout
+
+
 @pytest.mark.parametrize("P,flags,mode", [(1, [], "allgather"), (2, [], "allgather"), (2, ["-S", "x"], "halo"),
                                           (4, [], "rounds")])
 def test_cli_row_partition_matches_dist_oracle(pkg, oracle, tmp_path, P, flags, mode):
