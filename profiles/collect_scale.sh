@@ -7,7 +7,9 @@
 # N = 1, 2, 4, 8  x  exchange schedule {allgather (K pieces, default), rounds (the reference's broadcast pipeline,
 # src/cuda_utils.hpp:57-92), halo}  x  overlap {on, off = the reference's -S}.  Every line carries
 # comm{backend, world_size, devices[], rccl_version, exchange_ms, exposed_ms, overlap_frac} (bench.py: comm_report).
-# MGGCN_COMM_TRANSPORT does not apply here (one process per GPU over torch.distributed = RCCL).
+# The Python ranks exchange over torch.distributed = RCCL; every N > 1 line also carries the drop-in CLI's epoch on the same files in
+# three legs (cli_*: one enqueue thread per GPU over RCCL, cli_p2p_*: copy-engine peer copies, cli_serial_*: one host thread), each
+# with host_issue_ms -- the table below prints them.  bench.py starts its ranks itself (no launcher needed).
 set -u
 STEPS=${1:-20}
 WARMUP=${2:-3}
@@ -22,8 +24,7 @@ for N in 2 4 8; do
     for OV in "" "--no-overlap"; do
       PORT=$((PORT + 1))
       echo "N=$N mode=$MODE $OV" >&2
-      timeout -k 10 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 \
-        --master-port "$PORT" "$ROOT/bench.py" --gpus "$N" --steps "$STEPS" --warmup "$WARMUP" --mode "$MODE" $OV >> "$OUT" \
+      timeout -k 10 1500 python3 "$ROOT/bench.py" --gpus "$N" --steps "$STEPS" --warmup "$WARMUP" --mode "$MODE" $OV >> "$OUT" \
         || echo "{\"error\": \"N=$N mode=$MODE $OV\"}" >> "$OUT"
     done
   done
@@ -32,19 +33,20 @@ done
 for K in 1 2 8; do
   PORT=$((PORT + 1))
   echo "N=8 mode=allgather chunks=$K" >&2
-  timeout -k 10 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-    --master-port "$PORT" "$ROOT/bench.py" --gpus 8 --steps "$STEPS" --warmup "$WARMUP" --mode allgather --chunks "$K" >> "$OUT" \
+  timeout -k 10 1500 python3 "$ROOT/bench.py" --gpus 8 --steps "$STEPS" --warmup "$WARMUP" --mode allgather --chunks "$K" >> "$OUT" \
     || echo "{\"error\": \"N=8 allgather chunks=$K\"}" >> "$OUT"
 done
 python3 - "$OUT" <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
 base = next((r["value"] for r in rows if r.get("n_gpus") == 1), None)
-print("| N | mode (pieces) | overlap | epoch ms | speed-up | exchange ms / SpMM | exposed ms | overlap frac |\n|---|---|---|---|---|---|---|---|")
+print("| N | mode (pieces) | overlap | epoch ms | speed-up | exchange ms / SpMM | exposed ms | overlap frac | CLI rccl ms (host issue) | CLI p2p ms | CLI one-thread ms (host issue) |\n|---|---|---|---|---|---|---|---|---|---|---|")
 for r in rows:
     if "error" in r:
         print("|", r["error"], "| failed |||||||"); continue
     c = r.get("comm") or {}
     print(f"| {r['n_gpus']} | {c.get('mode', '-')} ({c.get('chunks') or 'default'}) | {c.get('overlap', '-')} | {r['value']:.3f} | "
-          f"{(base / r['value']) if base else float('nan'):.2f} | {c.get('exchange_ms', '-')} | {c.get('exposed_ms', '-')} | {c.get('overlap_frac', '-')} |")
+          f"{(base / r['value']) if base else float('nan'):.2f} | {c.get('exchange_ms', '-')} | {c.get('exposed_ms', '-')} | {c.get('overlap_frac', '-')} | "
+          f"{r.get('cli_epoch_ms', r.get('cli_error', '-'))} ({r.get('cli_host_issue_ms', '-')}) | {r.get('cli_p2p_epoch_ms', r.get('cli_p2p_error', '-'))} | "
+          f"{r.get('cli_serial_epoch_ms', r.get('cli_serial_error', '-'))} ({r.get('cli_serial_host_issue_ms', '-')}) |")
 PY
