@@ -128,7 +128,7 @@ def run_cli_epochs(pkg, indptr, indices, data, X, Y, hidden, epochs=8):
         if r is None or "error" in r:
             return r
         return {"cli_epoch_ms": r["epoch_ms"], "cli_setup_s": r["setup_s"], "cli_loss_first": r["loss_first"], "cli_epochs": r["epochs"],
-                # the reference's canonical run is the default TWENTY epochs (src/main.cpp:56): what that costs end to end here --
+                # the reference's canonical run is the default TWENTY epochs (src/main.cpp:52): what that costs end to end here --
                 # start-up (files, normalise / transpose, four SpMM plans) dwarfs the training at this size
                 "cli_default_run_s": round(r["setup_s"] + 20 * r["epoch_ms"] * 1e-3, 2)}
     finally:
