@@ -10,8 +10,9 @@
 //   p2p   device-to-device copies (hipMemcpyPeerAsync over xGMI: copy engines, no compute
 //         unit is taken from the SpMM that runs meanwhile; same-device copies when ranks share
 //         a GPU) ordered by events, PER PAIR: receiver j pulls from sender i as soon as i's
-//         stream has produced the piece (`ready`), every pull on its own per-peer stream so
-//         that the seven links of a GPU work at once; nobody waits for a third rank.  A sender
+//         stream has produced the piece (`ready`), every pull from another GPU on its own
+//         per-peer stream so that the seven links of a GPU work at once (ranks that share a
+//         device pull on the caller's stream); nobody waits for a third rank.  A sender
 //         may overwrite what it sent once its readers are done: that wait is either issued
 //         right after the exchange (default: NCCL's contract) or deferred to an explicit
 //         mggcn_comm_release (MGGCN_COMM_DEFER_RELEASE: the host layer releases on the
@@ -282,10 +283,13 @@ MGGCN_API mggcn_comm *mggcn_comm_init_all(int P, const int *devices) {
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) CHECK_HIP(e);
             (void)hipGetLastError();
         }
-    // one pulling stream per (receiver, sender) pair so that a GPU's links work side by side; MGGCN_P2P_PEER_STREAMS=0:
-    // every rank pulls on the caller's stream, one copy after the other (the round-3 form)
+    // One pulling stream per (receiver, sender) pair ON DIFFERENT GPUs, so that a GPU's links work side by side.  Ranks that
+    // share a device pull from each other on the caller's stream, one copy after the other: there is no link to keep busy, and
+    // eight ranks x seven extra streams on ONE card doubled the epoch of `mg_gcn -P 8` there (105.9 against 52.1 ms: the runtime
+    // multiplexes the streams over four hardware queues; profiles/experiments/cli_p8_variants_r04.log).
+    // MGGCN_P2P_PEER_STREAMS=0: never; =1: always, same device or not (tests: the only way to run this path on a one-GPU box).
     const char *ps = std::getenv("MGGCN_P2P_PEER_STREAMS");
-    const bool peer_streams = !(ps && std::atoi(ps) == 0) && P > 2;
+    const int peer_mode = ps ? std::atoi(ps) : -1;                 // -1: across devices only
     for (int j = 0; j < P; j++) {
         c->rk.push_back(std::make_unique<rank_state>());
         rank_state &r = *c->rk.back();
@@ -299,8 +303,8 @@ MGGCN_API mggcn_comm *mggcn_comm_init_all(int P, const int *devices) {
         r.peer_done.assign(P, nullptr);
         int least = 0, greatest = 0;
         CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        for (int i = 0; i < P && peer_streams; i++) {
-            if (i == j) continue;
+        for (int i = 0; i < P && peer_mode != 0 && P > 2; i++) {
+            if (i == j || (peer_mode < 0 && c->devices[i] == c->devices[j])) continue;
             CHECK_HIP(hipStreamCreateWithPriority(&r.peer_stream[i], hipStreamNonBlocking, greatest));
             CHECK_HIP(hipEventCreateWithFlags(&r.peer_done[i], hipEventDisableTiming));
         }

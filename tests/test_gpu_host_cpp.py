@@ -103,6 +103,15 @@ def test_cpp_dist_classes_on_odd_shapes(shape):
     assert r.stdout.count("TEST PASSED") >= 12, r.stdout
 
 
+def test_cpp_dist_per_peer_pulling_streams():
+    """MGGCN_P2P_PEER_STREAMS=1: every (receiver, sender) pair pulls on a stream of its own even when the ranks share a device --
+    the form the peer-copy transport takes by itself only between DIFFERENT GPUs (one stream per xGMI link); forced here so that
+    the fork / join event plumbing of csrc/comm.cpp runs on a one-GPU box: every schedule at 1e-4, bit-identical both ways."""
+    r = _run([os.path.join(BIN, "test_dist"), "4"], env={"MGGCN_OVERSUBSCRIBE": "1", "MGGCN_P2P_PEER_STREAMS": "1"})
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "TEST FAILED" not in r.stdout and r.stdout.count("TEST PASSED") >= 12, r.stdout
+
+
 def test_cpp_dist_many_pieces_wrap_the_event_ring():
     """40 pieces per SpMM and ONE release at its end: more exchanges in a row than the peer-copy transport has event slots per
     rank (32) -- slots are re-used, ranks that are 16 exchanges behind with their releases release on the spot
