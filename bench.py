@@ -113,6 +113,30 @@ def cli_leg(dataset_dir, cwd, hidden, flags=(), env=None, epochs=8, timeout=300)
     out.update(info)
     if len(issue) >= 3:
         out["host_issue_ms"] = round(float(np.median(issue[2:])), 4)
+    # the CLI's own per-epoch timer dump (csvs/<name>_<sizes>_<P>.csv, reference src/main.cpp:100-111, :168; lines
+    # "<epoch>_<rank>_<timer>:<ms>"): rank 0's SpMM and GEMM timers of the LAST epoch -- on the compute stream, so an SpMM's
+    # figure includes whatever it waited for its pieces
+    try:
+        import glob
+        last = str(len(ep) - 1)
+        spmm = gemm = 0.0
+        seen = False
+        for path in glob.glob(os.path.join(cwd, "csvs", "*.csv")):
+            for ln in open(path):
+                name, _, val = ln.strip().rpartition(":")
+                parts = name.split("_")
+                if len(parts) < 3 or parts[0] != last or parts[1] != "0":
+                    continue
+                if name.endswith("_matmul-spmm") and parts[-2] in ("0", "1") and len(parts) == 5:     # "<e>_<rank>_<layer>_<0|1>_matmul-spmm"
+                    spmm += float(val); seen = True
+                elif name.endswith("_matmul-gemm") and len(parts) == 5:
+                    gemm += float(val)
+            os.remove(path)                              # the next leg writes its own
+        if seen:
+            out["rank0_spmm_ms_per_epoch"] = round(spmm, 4)
+            out["rank0_gemm_ms_per_epoch"] = round(gemm, 4)
+    except Exception:                                    # noqa: BLE001 -- a diagnostic, never worth the line
+        pass
     return out
 
 

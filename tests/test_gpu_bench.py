@@ -67,6 +67,8 @@ def test_bench_multi_rank_rehearsal_prints_one_json_line():
     # (two ranks wrapped over this box's one GPU: peer-copy transport, one enqueue thread per rank)
     assert out["cli_epoch_ms"] > 0 and out["cli_epochs"] == 8 and out["cli_setup_s"] >= 0
     assert out["cli_transport"] == "p2p" and out["cli_enqueue_threads"] == 1
+    assert out["cli_host_issue_ms"] > 0 and out["cli_rank0_spmm_ms_per_epoch"] > 0 and out["cli_rank0_gemm_ms_per_epoch"] > 0
+    assert out["cli_rank0_spmm_ms_per_epoch"] < out["cli_epoch_ms"] * 1.05            # rank 0's SpMM timers of one epoch fit in the epoch
     # same data, same seed-99 parameters, same padded class count: the two forms start at the same loss
     assert abs(out["cli_loss_first"] - out["loss_first_last"][0]) <= 1e-4 * out["loss_first_last"][0]
 
