@@ -135,10 +135,12 @@ void mggcn_spmm_plan_destroy(mggcn_spmm_plan *plan);
  * its own passes over cores / n instead of all the cores (MGGCN_HOST_THREADS in the environment still wins).  Set it back
  * to 1 afterwards.  Process-wide. */
 void mggcn_spmm_plan_concurrent_builders(uint32_t n);
-/* Plans built from now on size their launch rounds to leave n compute units' worth of wave slots free: for SpMMs that run
- * while a collective kernel (RCCL) shares the device -- a round of exactly the resident set would end in a second, nearly
- * empty pass for the workgroups the foreign kernel displaced (+57 % measured).  The distributed host
- * layers set 16 around their plan builds and 0 afterwards; MGGCN_SPMM_RESERVED_CUS in the environment overrides.  Process-wide. */
+/* Plans built from now on leave at least n compute units' worth of wave slots free in EVERY launch round: for SpMMs that run
+ * while a collective kernel (RCCL) shares the device -- a round of exactly the resident set would end in a second, nearly empty
+ * pass for the workgroups the foreign kernel displaced (+57 % measured).  A minimum, not a cut: a matrix
+ * whose tasks leave that room anyway (one round, not full) keeps the full round size; only plans whose rounds would be full are
+ * built on smaller rounds (fewer waves in flight: -5 % when nobody shares the device).  The distributed host layers set 12
+ * around their plan builds and 0 afterwards; MGGCN_SPMM_RESERVED_CUS in the environment overrides.  Process-wide. */
 void mggcn_spmm_plan_reserved_cus(uint32_t n);
 /* introspection (tests, DESIGN.md figures) */
 uint32_t mggcn_spmm_plan_num_items(const mggcn_spmm_plan *plan);

@@ -564,8 +564,21 @@ Split choose_split_thin(uint32_t K) {
 // Tall reductions: fill the resident slots (2 workgroups per CU: 168-172 VGPRs) with K-slices, and
 // never exceed them -- 515 blocks on 512 slots run a second round for three blocks
 // (G_W = X^T G, M = 608: 103 slices 687 us, 102 slices 501 us; profiles/experiments/gemm_splits.py).
+// Tile width: 128 columns per workgroup when N allows -- unless that tiling leaves most of the chip idle and the product is
+// too short for split-K to make up for it (K < 16 steps): a rank's share at P = 8 of the hidden-layer products,
+// [29 121 x 128] . [128 x 128], is 228 workgroups of 512 threads at two per CU -- 114 of 256 CUs.  64-wide tiles double the
+// workgroups (the A tile is read twice, from L2).  The single-GPU shapes (M = 232 968: 1 821 tiles) are not touched.
+uint32_t pick_bn(uint32_t M, uint32_t N, uint32_t K) {
+    if (N <= 64) return 64;
+    static const bool always_wide = [] { const char *e = std::getenv("MGGCN_GEMM_WIDE_TILES"); return e && std::atoi(e) != 0; }();   // experiment knob
+    if (always_wide) return 128;
+    const uint64_t tiles128 = (uint64_t)((M + BM - 1) / BM) * ((N + 127) / 128);
+    const uint32_t k_steps = (K + BK - 1) / BK;
+    return (tiles128 < (uint64_t)kNumCU && k_steps < 16) ? 64 : 128;
+}
+
 Split choose_split(uint32_t M, uint32_t N, uint32_t K) {
-    const uint32_t bn = N > 64 ? 128 : 64;
+    const uint32_t bn = pick_bn(M, N, K);
     const uint64_t tiles = (uint64_t)((M + BM - 1) / BM) * ((N + bn - 1) / bn);
     const uint32_t k_steps = (K + BK - 1) / BK;
     uint32_t splits = 1;
@@ -701,7 +714,7 @@ void gemm_dispatch(mggcn_stream_t stream, int trans_a, int trans_b, uint32_t M, 
     const bool a_vec = aligned16(A) && lda % 4 == 0 && (trans_a ? M : K) % 4 == 0;
     const bool b_vec = aligned16(B) && ldb % 4 == 0 && (trans_b ? K : N) % 4 == 0;
     const bool a_kc = !trans_a, b_kc = trans_b != 0;
-    const int bn = N > 64 ? 128 : 64;
+    const int bn = (int)pick_bn(M, N, K);
     const dim3 grid((M + BM - 1) / BM, (N + bn - 1) / bn, sp.splits);
 
     const dim3 blk(512);

@@ -264,25 +264,35 @@ bool sweep_build_host(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr, 
     // 64 MiB slices: 2.69 ms (3 blocks/CU 3.11, 5 -> 3.56; the float4 kernels hold 128 VGPRs, so
     // four blocks of four waves is also what fits).
     const uint32_t blocks_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u), 8u));
-    // Compute units' worth of wave slots a launch round leaves free for a kernel that SHARES the device with the SpMM -- the
-    // channels of a collective (RCCL) kernel: every workgroup of it that sits on a CU displaces one of the four SpMM workgroups
-    // there, and a round of EXACTLY the resident set then ends in a second, nearly empty pass.  Measured with a stand-in
-    // (profiles/experiments/coresident_r04.log; rank 0's share of the Reddit shape at P = 2, two full rounds per SpMM): 1.29 ms
-    // alone, 2.01 ms next to as few as 16 foreign workgroups; with 16 CUs reserved 1.32 ms alone and 1.25-1.27 ms next to 16-64
-    // of them.  Set per plan build by the distributed host layers (mggcn_spmm_plan_reserved_cus), MGGCN_SPMM_RESERVED_CUS
-    // overrides; 0 = the device is ours (every single-GPU plan).
+    // Room for a kernel that SHARES the device with the SpMM -- the channels of a collective (RCCL) kernel: every workgroup of it
+    // that sits on a CU displaces one of the four SpMM workgroups there, and a round of EXACTLY the resident set then ends in a
+    // second, nearly empty pass.  Measured with a stand-in (profiles/experiments/coresident_r04.log; rank 0's share of the Reddit
+    // shape at P = 2, two full rounds per SpMM): 1.29 ms alone, 2.01 ms next to as few as 16 foreign workgroups; with room left,
+    // 1.25-1.27 ms next to 16-64 of them.  `reserved` = compute units' worth of wave slots EVERY launch round must leave free
+    // (set per plan build by the distributed host layers, mggcn_spmm_plan_reserved_cus; MGGCN_SPMM_RESERVED_CUS overrides; 0 =
+    // the device is ours: every single-GPU plan).  It is a minimum, not a cut: a matrix whose tasks leave that room anyway --
+    // one round, not full: a rank's pieces at P = 4 / 8 -- keeps the full round size (fewer waves in flight cost 3-6 % when
+    // nobody shares the device, rank_epoch_reserve_ab_r04.log); only plans whose rounds would be full are built on smaller rounds.
     const uint32_t reserved = std::min(env_u32("MGGCN_SPMM_RESERVED_CUS", g_reserved_cus.load(std::memory_order_relaxed)), num_cu - 1u);
-    const uint32_t round_tasks = (num_cu - reserved) * blocks_per_cu * kWavesPerBlock;
+    const uint32_t full_round = num_cu * blocks_per_cu * kWavesPerBlock, reserved_tasks = reserved * blocks_per_cu * kWavesPerBlock;
+    uint32_t round_tasks = full_round;
 
     // (MGGCN_SPMM_SWEEP_ROWS_PER_TASK caps it for experiments: 8 rows per wave -- twice the launches,
     //  same slices -- ran 2.88 ms against 2.69 at 16, 4 rows 3.00: profiles/experiments/sweep_rows_per_task_r01.log)
     // 1. virtual rows: slices of heavy rows get partial-sum slots
     // rows per task: 16 when there are enough rows to fill a round, fewer for small row blocks
     // (a rank's share at P = 8 has 29 k rows: 16 rows per wave would leave 7 waves per CU)
-    const uint32_t cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(std::min<uint32_t>((uint32_t)kRW, std::max(1u, env_u32("MGGCN_SPMM_SWEEP_ROWS_PER_TASK", (uint32_t)kRW))), (n_rows + round_tasks - 1) / round_tasks));
-    const uint32_t t_est = (n_rows + cap_rows - 1) / cap_rows;
-    const uint32_t target = (uint32_t)std::max<uint64_t>(1, nnz / t_est);
-    const uint32_t split = std::max<uint32_t>(256u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_SPLIT", target / 2), 1u << 20));
+    const uint32_t cap_limit = std::min<uint32_t>((uint32_t)kRW, std::max(1u, env_u32("MGGCN_SPMM_SWEEP_ROWS_PER_TASK", (uint32_t)kRW)));
+    uint32_t cap_rows = 1;
+    auto first_cap = [&] { cap_rows = std::max<uint32_t>(1u, std::min<uint32_t>(cap_limit, (n_rows + round_tasks - 1) / round_tasks)); };
+    first_cap();
+    uint32_t t_est = 0, target = 0, split = 0;
+    auto derive_split = [&] {
+        t_est = (n_rows + cap_rows - 1) / cap_rows;
+        target = (uint32_t)std::max<uint64_t>(1, nnz / t_est);
+        split = std::max<uint32_t>(256u, std::min<uint32_t>(env_u32("MGGCN_SPMM_SWEEP_SPLIT", target / 2), 1u << 20));
+    };
+    derive_split();
     std::vector<VRow> vrows;
     vrows.reserve((size_t)n_rows + 4096);
     std::vector<SweepSplitRow> &split_rows = P.split_rows;
@@ -322,6 +332,10 @@ bool sweep_build_host(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr, 
         }
     };
     if (XS == 1) {
+      for (;;) {
+        vrows.clear();
+        split_rows.clear();
+        n_slots = 0;
         for (uint32_t r = 0; r < n_rows; r++) {
             const uint32_t b = indptr[r], e = indptr[r + 1];
             require(e >= b, "indptr must be non-decreasing");
@@ -343,6 +357,24 @@ bool sweep_build_host(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr, 
         }
         // 2. tasks
         T = (uint32_t)((vrows.size() + cap_rows - 1) / cap_rows);
+        // A launch round that is slightly over-full (the slices of heavy rows count as rows too) would become TWO rounds of
+        // half-length tasks -- every per-task cost twice and a second launch: a rank's backward pieces at P = 8 ran 12 % slower
+        // that way once 16 CUs' worth of slots were reserved (profiles/experiments/rank_epoch_reserve_ab_r04.log).  One more
+        // row per task keeps it one round.
+        if (T > round_tasks && T <= round_tasks + round_tasks / 4 && cap_rows < cap_limit) {
+            cap_rows++;
+            derive_split();
+            continue;
+        }
+        // the room asked for: one round with at least that many free slots, or every round on the smaller size
+        if (reserved_tasks && round_tasks == full_round && (T > full_round || full_round - T < reserved_tasks)) {
+            round_tasks = full_round - reserved_tasks;
+            first_cap();
+            derive_split();
+            continue;
+        }
+        break;
+      }
         if (T > round_tasks) T = (T + round_tasks - 1) / round_tasks * round_tasks;
         T = std::max<uint32_t>(T, 1u);
         bins.resize(T);

@@ -603,12 +603,12 @@ class dist_sparse_linear:
     def _plan(self, ctx: context, key, M: csr_matrix, d: int):
         pl = self.plans.get(key)
         if pl is None:
-            # with more than one rank these SpMMs run while RCCL's kernels share the device: their launch rounds leave 16
-            # CUs' worth of wave slots free (include/mggcn.h: mggcn_spmm_plan_reserved_cus; +57 % per SpMM without, measured
+            # with more than one rank these SpMMs run while RCCL's kernels share the device: their launch rounds leave (at least)
+            # 12 CUs' worth of wave slots free (include/mggcn.h: mggcn_spmm_plan_reserved_cus; +57 % per SpMM without, measured
             # with a stand-in: profiles/experiments/coresident_r04.log)
             shared = self._shared_device
             if shared:
-                ctx.lib.mggcn_spmm_plan_reserved_cus(16)
+                ctx.lib.mggcn_spmm_plan_reserved_cus(12)
             try:
                 pl = self.plans[key] = ops.spmm_plan_for(ctx, M, max(d, 128), d)     # shared across layers
             finally:
@@ -1020,11 +1020,11 @@ class dist_gcn:
 
     def __call__(self, dctx, H):
         if self._plan_wants:
-            # with more than one rank these SpMMs run while RCCL's kernels share the device: launch rounds that leave 16 CUs'
-            # worth of wave slots free (include/mggcn.h: mggcn_spmm_plan_reserved_cus; profiles/r04_forced_dist_summary.md)
+            # with more than one rank these SpMMs run while RCCL's kernels share the device: launch rounds that leave (at least) 12
+            # CUs' worth of wave slots free (include/mggcn.h: mggcn_spmm_plan_reserved_cus; profiles/r04_forced_dist_summary.md)
             shared = dctx.P > 1 and dctx.overlap
             if shared:
-                dctx.ctx.lib.mggcn_spmm_plan_reserved_cus(16)
+                dctx.ctx.lib.mggcn_spmm_plan_reserved_cus(12)
             try:
                 ops.prebuild_plans(dctx.ctx, self._plan_wants)
             finally:

@@ -157,10 +157,10 @@ dist_spmm_buffers get_matmul_buffer(const dist_context ctx, const dist_row_csr_m
     out.block.resize(P);
     out.piece.resize(P);
     // these SpMMs run while the exchange's kernels (RCCL channels, the peer-copy transport's sums) share the device: their launch
-    // rounds leave 16 CUs' worth of wave slots free (include/mggcn.h: mggcn_spmm_plan_reserved_cus)
+    // rounds leave (at least) 12 CUs' worth of wave slots free (include/mggcn.h: mggcn_spmm_plan_reserved_cus)
     struct reserve_scope {
         bool on;
-        explicit reserve_scope(bool on) : on(on) { if (on) mggcn_spmm_plan_reserved_cus(16); }
+        explicit reserve_scope(bool on) : on(on) { if (on) mggcn_spmm_plan_reserved_cus(12); }
         ~reserve_scope() { if (on) mggcn_spmm_plan_reserved_cus(0); }
     } reserve(P > 1 && ctx.overlap);
     {   // every rank's plans of this width, built side by side (csr_matrix::prebuild_plans), then picked up below

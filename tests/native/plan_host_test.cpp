@@ -147,7 +147,7 @@ static void check_sweep(const Csr &A, const uint32_t *ip, const uint32_t *ix, co
     if (!ok) return;
     const bool narrow = d_hint >= 1 && d_hint <= 64;
     CHECK(h.n_tasks == h.tasks.size() && h.task_rows.size() == (size_t)h.n_tasks * kRW && h.n_entries == h.entries.size());
-    CHECK(h.round_tasks == (num_cu - std::min(env_u32("MGGCN_SPMM_RESERVED_CUS", 0u), num_cu - 1u)) * env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u) * kWavesPerBlock);
+    CHECK(h.round_tasks == num_cu * env_u32("MGGCN_SPMM_SWEEP_BLOCKS_PER_CU", 4u) * kWavesPerBlock);       // nothing reserved in these runs
     CHECK(((h.prio_bits_wide >> kNumCuPos) & kNumCuMask) == num_cu && ((h.prio_bits_narrow >> kNumCuPos) & kNumCuMask) == num_cu);
     CHECK(narrow ? (h.lpe == 4 || h.lpe == 8 || h.lpe == 12 || h.lpe == 16) && h.run_pad == 64 / h.lpe : h.lpe == 0 && h.run_pad == 2);
     const uint32_t G = h.run_pad;
@@ -278,6 +278,30 @@ static void test_column_stats(const Csr &A) {
     CHECK(std::fabs(cs.locality - (double)near / (double)A.ix.size()) < 1e-12);
 }
 
+// ---- reserved compute units: a minimum of free slots per launch round, not a cut -------------------------------------------
+static void test_reserved_cus() {
+    const Csr A = make_csr(3000, 3000, 24, 0, 4242, true);
+    auto build = [&](uint32_t num_cu, unsigned reserved) {
+        set_reserved_cus(reserved);
+        SweepHost h;
+        CHECK(sweep_build_host(A.n, A.m, A.ip.data(), A.ix.data(), A.v.data(), 128, true, 0, true, num_cu, h));
+        set_reserved_cus(0);
+        return std::make_pair(h.round_tasks, h.n_tasks);
+    };
+    // 256 CUs: 3000 rows are ONE round of 4096 slots with a thousand to spare -- the room is there, the round keeps its size
+    auto [r0, t0] = build(256, 0);
+    auto [r1, t1] = build(256, 12);
+    CHECK(r0 == 4096 && r1 == 4096 && t0 == t1 && t1 <= 4096 - 12 * 16);
+    // 8 CUs: 128 slots per round, several full rounds -- every round shrinks to (8 - 2) x 16 slots
+    auto [r2, t2] = build(8, 0);
+    auto [r3, t3] = build(8, 2);
+    CHECK(r2 == 128 && t2 % 128 == 0 && r3 == 96 && t3 % 96 == 0);
+    // one round that would be nearly full: 33 CUs = 528 slots, 3000 rows at 6 per task = 500 tasks -> 28 free < 32 asked -> smaller rounds
+    auto [r4, t4] = build(33, 0);
+    auto [r5, t5] = build(33, 2);
+    CHECK(r4 == 528 && t4 <= 528 && 528 - t4 < 32 && r5 == 496 && (t5 <= 496 || t5 % 496 == 0));
+}
+
 // ---- host_prep against the oracle ----------------------------------------------------------------------
 static void test_host_prep(const Csr &A0, uint32_t P) {
     Csr A = A0;
@@ -387,6 +411,11 @@ int main() {
         std::printf("%s: plan builders + host prep on %u x %u, kind %d, %zu non-zeros\n", g_failures == before ? "TEST PASSED" : "TEST FAILED",
                     s.n, s.m, s.kind, A.ix.size());
         idx++;
+    }
+    {
+        const int before = g_failures;
+        test_reserved_cus();
+        std::printf("%s: reserved compute units\n", g_failures == before ? "TEST PASSED" : "TEST FAILED");
     }
     {
         const int before = g_failures;
