@@ -375,7 +375,15 @@ bool sweep_build_host(uint32_t n_rows, uint32_t n_cols, const uint32_t *indptr, 
         }
         break;
       }
-        if (T > round_tasks) T = (T + round_tasks - 1) / round_tasks * round_tasks;
+        if (T > round_tasks) {
+            T = (T + round_tasks - 1) / round_tasks * round_tasks;
+        } else {
+            // ONE round: use every wave slot it has (minus the room asked for) -- the kernels are bound by what sixteen waves per
+            // CU get through the texture path, and ceil(rows / rows-per-task) tasks left 11 % of the slots of a rank's pieces at
+            // P = 8 empty (3 641 of 4 096).  The same rows over more bins: shorter tasks, all of them in flight.
+            const uint32_t avail = round_tasks == full_round ? full_round - reserved_tasks : round_tasks;
+            T = std::max<uint32_t>(T, std::min<uint32_t>(avail, (uint32_t)vrows.size()));
+        }
         T = std::max<uint32_t>(T, 1u);
         bins.resize(T);
         std::vector<uint32_t> all(vrows.size());

@@ -37,7 +37,7 @@ class rank0_of(D.dist_context):
 
 
 base = None
-for P in (1, 2, 4, 8):
+for P in [int(x) for x in os.environ.get("RANK_EPOCH_P", "1,2,4,8").split(",")]:
     dctx = rank0_of(P)
     p = D.partition_bounds(n, P)
     sizes = [X.shape[1], 128, 128, 128, (C + P - 1) // P * P]
