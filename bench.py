@@ -193,9 +193,11 @@ def multi_gpu_env(env, world):
     """Environment every multi-process / multi-GPU leg needs (set here, not left to the caller):
       HSA_ENABLE_IPC_MODE_LEGACY=0  the host driver of this pool only supports dmabuf IPC; without it RCCL's (and
                                     torch's) cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`
+      NCCL_DEBUG=WARN               (unless set) RCCL's warnings go to stderr
       MGGCN_HOST_THREADS            the N ranks share one host: every rank builds up to four SpMM plans side by side and
                                     each plan builder starts MGGCN_HOST_THREADS threads (default: every core it sees)"""
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_DEBUG", "WARN")               # RCCL's own warnings on stderr: a first multi-GPU run should say why it failed
     if "MGGCN_HOST_THREADS" not in env:
         try:
             avail = len(os.sched_getaffinity(0))
