@@ -459,6 +459,27 @@ def main():
     if multi:
         out["comm"] = comm_report(torch, dist, dctx, G, epoch, rehearsal, local_rank, spmm_timers, args)
         out["comm"]["high_priority_stream"] = high_priority_comm
+        out["comm"]["chunks"] = out["comm"].get("chunks") or D.default_chunks(P)
+        if P > 1 and args.mode == "allgather" and not args.no_extras:
+            # the same epoch with the OTHER piece count (2 <-> 4): how many pieces pay depends on what the links deliver against
+            # what a piece costs the compute stream (model: profiles/experiments/rank_epoch_model_r04.log) -- one more data point
+            # per N from the same run; never the headline.  Every rank takes part (the ranks re-load their rows: collectives).
+            alt = 2 if D.default_chunks(P) != 2 else 4
+            G = None
+            Ad2, A_Td2, Xd2, Yd2, _ = D.load_rank_local(dctx, tmp, chunks=alt)
+            G2 = D.dist_gcn(dctx, Ad2, A_Td2, sizes, fused=fused, mode=args.mode)
+            for _ in range(2):
+                G2.train_step(dctx, Xd2, Yd2, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+            barrier()
+            t_a = time.perf_counter()
+            for _ in range(args.steps):
+                G2.train_step(dctx, Xd2, Yd2, 1e-2, 0.9, 0.999, 5e-4, 1e-8)
+            barrier()
+            ms_a = (time.perf_counter() - t_a) * 1e3 / max(args.steps, 1)
+            t = torch.tensor([ms_a], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out["alt_chunks"] = {"chunks": alt, "epoch_ms": round(float(t.item()), 4)}
+            G2 = Ad2 = A_Td2 = Xd2 = Yd2 = None
     if rank == 0 and not multi and not args.no_extras:
         # (1) the reference's own interface on the same workload: never the headline (it synchronises inside the loss
         #     like the reference, src/gcn.hpp:816; `value` goes through gcn.train_step with one sync per epoch)

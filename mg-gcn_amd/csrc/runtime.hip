@@ -118,10 +118,11 @@ __global__ __launch_bounds__(256) void occupy_kernel(const volatile uint32_t *st
     // (the flag is looked at every ~50 us: sixty-four waves polling a host-memory word back to back delay every packet the
     // command processor fetches over the same path -- the first version of this stand-in slowed the LAUNCHES it was meant to
     // share the device with by 20 us per workgroup of its own)
+    // the clock is read after every sleep (~3.5 us: the kernel also serves as a calibrated delay, rank_epoch_model_r04.py)
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < max_ticks) {
-        for (int k = 0; k < 16; k++) __builtin_amdgcn_s_sleep(127);
-        if (*stop) break;
+    for (unsigned it = 1; __builtin_amdgcn_s_memrealtime() - t0 < max_ticks; it++) {
+        __builtin_amdgcn_s_sleep(127);
+        if ((it & 15u) == 0 && *stop) break;
     }
 }
 }  // namespace

@@ -123,8 +123,11 @@ def default_chunks(P: int) -> int:
     diagonal block (1/P of the work) overlaps the exchange; with K pieces the SpMM over piece c
     runs while piece c+1 is still on the wire.  Two pieces at P = 2 (one xGMI link between the pair:
     60 MB per exchange is of the order of the diagonal block's 0.7 ms, so half the remote block should
-    start early), four from P = 3 on (the cut costs no compute: -1 % / -7 % at P = 4 / 8,
-    profiles/experiments/rank_share.py).  Override with MGGCN_DIST_CHUNKS."""
+    start early), four from P = 3 on.  A piece is not free: rank 0's whole epoch at P = 8 with the exchange switched off is
+    2.96 / 3.04 / 3.08 / 3.25 / 3.57 ms with 1 / 2 / 3 / 4 / 6 pieces (launches, partial-sum combines, one more pass over C
+    each); with the exchange modelled as a delay at 7 x 50 GB/s it is 4.54 / 3.74 / 3.53 / 3.54 / 3.69 ms, at 7 x 36 GB/s
+    5.23 / 4.32 / 4.10 / 4.03 / 4.05 -- three or four pieces at P = 8, four at P = 4 (3 links), two or three at P = 2 (one link):
+    profiles/experiments/rank_epoch_model_r04.log.  Override with MGGCN_DIST_CHUNKS."""
     import os
     env = os.environ.get("MGGCN_DIST_CHUNKS")
     if env:

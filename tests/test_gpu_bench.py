@@ -63,6 +63,7 @@ def test_bench_multi_rank_rehearsal_prints_one_json_line():
     assert [d["rank"] for d in comm["devices"]] == [0, 1] and all("name" in d and "device" in d for d in comm["devices"])
     assert comm["mode"] == "allgather" and comm["overlap"] is True and "rccl_version" in comm
     assert comm["exchange_ms"] > 0 and comm["exposed_ms"] >= 0 and comm["overlap_frac"] is not None
+    assert comm["chunks"] == 2 and out["alt_chunks"]["chunks"] == 4 and out["alt_chunks"]["epoch_ms"] > 0      # the other piece count, same run
     # the PRODUCT path next to it: `mg_gcn -P 2 -R 1 train <the same files>` after the ranks have let go of the GPU
     # (two ranks wrapped over this box's one GPU: peer-copy transport, one enqueue thread per rank)
     assert out["cli_epoch_ms"] > 0 and out["cli_epochs"] == 8 and out["cli_setup_s"] >= 0
