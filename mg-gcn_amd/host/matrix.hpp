@@ -12,11 +12,14 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <iostream>
 #include <map>
+#include <mutex>
 #include <ostream>
 #include <string>
 #include <tuple>
@@ -101,6 +104,40 @@ public:
             s_->gemm_ws_bytes = bytes;
         }
         return s_->gemm_ws.get();
+    }
+};
+
+// scope timer of the reference (src/matrix.hpp:160-187): prints "<name> has started" / "<name> took <ms>ms" when built with
+// -DLOG (CMake option LOG, src/CMakeLists.txt:10-13), silent otherwise; synchronises the context it is given before it
+// reads the clock.  The reference only instantiates it in its column-partition code (src/cuda_utils.hpp:213-226,
+// src/dist_matrix.hpp:359-367), which is out of scope here; the class is kept so that code written against it compiles.
+inline std::mutex timer__iomutex;
+
+template <typename ctx_t>
+class timer {
+    const std::string name;
+    const std::chrono::high_resolution_clock::time_point start;
+    ctx_t *ctx;
+    std::mutex &mtx;
+    std::ostream &os;
+
+public:
+    timer(std::string s, ctx_t *ctx = nullptr, std::mutex &mtx_ = timer__iomutex, std::ostream &os_ = std::cerr)
+        : name(std::move(s)), start(std::chrono::high_resolution_clock::now()), ctx(ctx), mtx(mtx_), os(os_) {
+#ifdef LOG
+        std::lock_guard<std::mutex> lock(mtx);
+        os << name << " has started" << std::endl;
+#endif
+    }
+    ~timer() {
+#ifdef LOG
+        std::lock_guard<std::mutex> lock(mtx);
+        if (ctx) ctx->sync();
+        os << name << " took " << time() * 1000 << "ms" << std::endl;
+#endif
+    }
+    double time() const {
+        return std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::high_resolution_clock::now() - start).count();
     }
 };
 

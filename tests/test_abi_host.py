@@ -442,3 +442,19 @@ def test_prep_command_line(pkg, tmp_path):
     assert len(ix) == A.nnz + 52                                                # + one self-loop per (padded) vertex
     rows = np.repeat(np.arange(52), np.diff(ip.astype(np.int64)))
     assert set(zip(rows.tolist(), ix.tolist())) == set(zip(ix.tolist(), rows.tolist()))   # pattern stays symmetric
+
+
+def test_cmake_front_builds_the_cli(tmp_path):
+    """mg-gcn_amd/CMakeLists.txt: the reference's target names (`mg_gcn_lib`, `mg_gcn`, option LOG; src/CMakeLists.txt:10-37) over
+    the prebuilt C-ABI libraries -- configures, builds and the binary answers -h without a GPU (with -DLOG=ON: the scope timer of
+    src/matrix.hpp:160-187 compiles in)."""
+    import shutil
+    if shutil.which("cmake") is None:
+        pytest.skip("no cmake")
+    b = tmp_path / "build"
+    r = subprocess.run(["cmake", "-S", os.path.join(ROOT, "mg-gcn_amd"), "-B", str(b), "-DLOG=ON"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(["cmake", "--build", str(b), "-j", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([str(b / "mg_gcn"), "-h"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "Usage" in r.stdout
