@@ -740,14 +740,17 @@ class dist_row_linear:
         self.W, self.b = repl_dn_matrix(dctx, in_, out), repl_dn_matrix(dctx, 1, out)
         # G_W and G_b live in ONE buffer: a single in-place all-reduce, no packing copies
         off_b = (in_ * out + 3) // 4 * 4                       # keep G_b 16-byte aligned
-        self.G_flat = _torch().empty(off_b + out, dtype=_torch().float32, device=dctx.ctx.device)
+        # ... and four more floats after G_b: the model's LAST layer carries the epoch's two loss sums through its gradient
+        # all-reduce there (dist_gcn.train_step: no collective of their own)
+        off_t = (off_b + out + 3) // 4 * 4
+        self.G_flat = _torch().zeros(off_t + 4, dtype=_torch().float32, device=dctx.ctx.device)
+        self.tail = self.G_flat[off_t:off_t + 2]
         self.G_W = repl_dn_matrix.__new__(repl_dn_matrix)
         self.G_W.local = dn_matrix(in_, out, self.G_flat)
         self.G_b = repl_dn_matrix.__new__(repl_dn_matrix)
         self.G_b.local = dn_matrix(1, out, self.G_flat[off_b:])
-        if off_b != in_ * out:
-            self.G_flat.zero_()                                # the padding takes part in the sum
-            _torch().cuda.current_stream().synchronize()        # torch zeroes on ITS stream; the kernels run on the context's
+        _torch().cuda.current_stream().synchronize()            # torch zeroes on ITS stream (the padding takes part in the sum);
+                                                                # the kernels run on the context's
         self._grad_pending = None
         self._dctx = dctx
         self.backward_out, self.fused = backward_out, fused
@@ -1011,6 +1014,7 @@ class dist_gcn:
                                                self.bcast_buffer, self.bcast_buffer2, fused, mode))
         link_fused_backward(self.layers_, fused)
         self.fused, self._adam = fused, None
+        self._loss_host = None                                 # pinned host copy of the epoch's two global loss sums (train_step)
         # this rank's SpMM plans, built side by side before the first epoch (ops.prebuild_plans) instead of one by one
         # inside it: the diagonal block and the pieces of the schedule that runs, both matrices, both widths
         self._plan_wants = []
@@ -1063,11 +1067,25 @@ class dist_gcn:
                    weight_decay, eps):
         """forward + loss + backward + Adam with ONE host synchronisation and the loss all-reduce at the
         end of the epoch (see gcn.train_step); the reference's loop body is src/main.cpp:159-166."""
+        torch = _torch()
         out = self(dctx, H)
         self.loss_layer(dctx, out, Y, sync=False)
-        self.backward(dctx)
+        # The two loss sums ride on the LAST layer's gradient all-reduce (four spare floats behind [G_W | G_b]) instead of a
+        # collective and a device-to-host copy of their own after the epoch's synchronisation: at P = 8 that turn-around was
+        # ~0.1 ms of idle GPU per 3.5-ms epoch.  (The reference adds its P managed scalars on the host, src/gcn.hpp:929.)
+        st = dctx.ctx.cuda_streams[0]
+        last = self.layers_[-1].lin
+        with torch.cuda.stream(st):
+            last.tail.copy_(self.loss_layer.inner.sums)
+        self.backward(dctx)                                    # ... -> finish_backward: the compute stream sees the summed buffers
         self.adam_update(dctx, lr, beta1, beta2, weight_decay, eps)
+        if self._loss_host is None:
+            self._loss_host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+        with torch.cuda.stream(st):
+            self._loss_host.copy_(last.tail, non_blocking=True)
         dctx.sync()
-        return self.loss_layer.read(dctx)
+        s = self._loss_host.numpy()
+        n = np.float32(self.loss_layer._n)
+        return float(np.float32(s[0]) / n), float(np.float32(s[1]) / n)
 
     def layers(self): return self.layers_

@@ -160,7 +160,9 @@ def test_python_ranks_c3_full_size(pkg, oracle, reddit_dirs):
     for rank, loss, acc, (loss1, loss2), grads, _, _ in res:
         assert abs(loss - want["loss"]) <= TOL * abs(want["loss"]), (rank, loss, want["loss"])
         assert loss == res[0][1] and (loss1, loss2) == res[0][3]          # one global loss on every rank
-        assert loss1 == loss and loss2 < loss1                            # deterministic forward; then it trains
+        # deterministic forward (train_step sums the ranks' loss terms inside the last layer's gradient all-reduce, train_forward
+        # in a collective of its own: the same four numbers added in a possibly different order); then it trains
+        assert abs(loss1 - loss) <= 1e-6 * abs(loss) and loss2 < loss1
     for (gw, gb), (ow, ob) in zip(res[0][4], want["grads"]):
         assert np.abs(gw - ow).max() <= TOL * np.abs(ow).max()
         assert np.abs(gb - ob).max() <= TOL * np.abs(ob).max()
