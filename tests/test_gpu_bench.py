@@ -52,6 +52,25 @@ def _rehearsal(args, port_env=None):
 
 
 @pytest.mark.gpu
+def test_bench_whose_ranks_fail_still_times_the_product_cli():
+    """A first contact of torch.distributed / RCCL with a node that fails must not cost the line: plain `python bench.py --gpus 2`
+    whose ranks exit without one (test hook MGGCN_BENCH_FAIL_RANKS) times `mg_gcn -P 2 -R 1 ...` on the same dataset from the
+    launching process and says so (`value_source`, `ranks_error`)."""
+    env = dict(os.environ, MGGCN_BENCH_REHEARSAL="1", MGGCN_BENCH_FAIL_RANKS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scale", "0.05"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _one_json_line(r.stdout)
+    assert REQUIRED <= set(out) and out["roofline"] is None
+    assert out["n_gpus"] == 2 and out["value"] == out["cli_epoch_ms"] > 0 and out["steps"] == out["cli_epochs"] - 2
+    assert "mg_gcn -P 2" in out["value_source"] and "exited with code" in out["ranks_error"]
+    assert out["cli_transport"] == "p2p" and out["cli_loss_first"] > 0
+    assert out["config"]["parallelism"] == "rows2-allgather" and out["config"]["sizes"][-1] % 2 == 0
+
+
+@pytest.mark.gpu
 def test_bench_multi_rank_rehearsal_prints_one_json_line():
     out = _rehearsal([])
     assert REQUIRED <= set(out)
