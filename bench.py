@@ -164,6 +164,7 @@ def run_cli_multi_gpu(dataset_dir, P, hidden, mode, overlap, rehearsal, epochs=8
     (src/main.cpp:134-170) -- on the files the Python ranks just trained on, after they have let go of the GPUs.  Legs:
       default  one enqueue thread per GPU, RCCL (grouped calls become per-thread calls)        -> cli_epoch_ms, cli_transport, ...
       p2p      same, exchange by peer copies on the copy engines (no compute unit taken from the SpMM)  -> cli_p2p_*
+      push     same, the SENDER copies (MGGCN_P2P_PUSH=1: writes over xGMI instead of reads)           -> cli_p2p_push_*
       serial   the reference's process model: ONE host thread issues every GPU's work, RCCL    -> cli_serial_*
       (N > 2)  peer copies pulled on one stream per rank instead of one per xGMI link              -> cli_p2p_one_stream_*
     Each leg is bounded (own session, killed on timeout); a failed leg reports its error and the next one still runs."""
@@ -176,6 +177,8 @@ def run_cli_multi_gpu(dataset_dir, P, hidden, mode, overlap, rehearsal, epochs=8
     threads = {"MGGCN_ENQUEUE_THREADS": "1"}
     legs = [("cli", threads)] if rehearsal else [("cli", threads), ("cli_p2p", dict(threads, MGGCN_COMM_TRANSPORT="p2p")),
                                                  ("cli_serial", {"MGGCN_ENQUEUE_THREADS": "0"})]
+    if not rehearsal:                    # ... the copies turned round: senders write into the receivers' buffers (posted writes over xGMI)
+        legs.append(("cli_p2p_push", dict(threads, MGGCN_COMM_TRANSPORT="p2p", MGGCN_P2P_PUSH="1")))
     if not rehearsal and P > 2:          # ... and the peer copies pulled on ONE stream per rank, copy after copy (are the per-peer streams worth it?)
         legs.append(("cli_p2p_one_stream", dict(threads, MGGCN_COMM_TRANSPORT="p2p", MGGCN_P2P_PEER_STREAMS="0")))
     out = {}
@@ -285,7 +288,7 @@ def cli_only_line(n, args, reason):
         shutil.rmtree(tmp, ignore_errors=True)
     if not cli:
         return None
-    leg = next((k for k in ("cli_p2p", "cli", "cli_serial") if f"{k}_epoch_ms" in cli), None)
+    leg = next((k for k in ("cli_p2p", "cli_p2p_push", "cli", "cli_serial") if f"{k}_epoch_ms" in cli), None)
     if leg is None:
         return None
     ms = cli[f"{leg}_epoch_ms"]

@@ -20,7 +20,10 @@
  * share a GPU) ordered by events PER PAIR: a receiver pulls a sender's piece as soon as that
  * sender's stream has produced it, every pull on its own per-peer stream; sums formed in rank order
  * on every GPU.  p2p is selected when two ranks share a GPU (RCCL refuses that: this is how the
- * P > 1 schedules run on a one-GPU box) or with MGGCN_COMM_TRANSPORT=p2p.
+ * P > 1 schedules run on a one-GPU box) or with MGGCN_COMM_TRANSPORT=p2p.  MGGCN_P2P_PUSH=1 turns
+ * the copies round ("p2p-push"): a sender writes its piece into the receiver's buffer as soon as
+ * that buffer is free, receivers only wait; what a sender may overwrite then depends on its own
+ * copies only (mggcn_comm_release waits for nobody else).
  *
  * Two families of entry points over the same transports:
  *   all ranks   (the reference's one-host-thread model) one call takes one buffer and one stream PER
@@ -51,7 +54,7 @@ typedef struct mggcn_comm mggcn_comm;
 mggcn_comm *mggcn_comm_init_all(int P, const int *devices);
 void mggcn_comm_destroy(mggcn_comm *comm);
 int mggcn_comm_size(const mggcn_comm *comm);
-/* "rccl" or "p2p" */
+/* "rccl", "p2p" (receivers read their pieces) or "p2p-push" (MGGCN_P2P_PUSH=1: senders write them) */
 const char *mggcn_comm_transport(const mggcn_comm *comm);
 
 /* Exchange flags (p2p transport; rccl ignores them), mggcn_comm_set_exchange_flags:

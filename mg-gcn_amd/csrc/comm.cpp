@@ -36,6 +36,19 @@
 // sequence counters are what orders "event recorded" before "event waited for".  Event slots
 // are reused every R exchanges: a rank that is R / 2 exchanges behind with its releases
 // releases on the spot, so a slot is never re-recorded while somebody still has to wait for it.
+//
+// MGGCN_P2P_PUSH=1 turns the copies round: the SENDER writes into the receiver's buffer (posted
+// writes over xGMI instead of read round trips; the copy runs on the sender's copy engines):
+//   begin(j)    as above: ready[j][s % R] now also says "my receive buffer is free" (everything
+//               that read it was queued on j's stream before)
+//   push(j)     for every receiver i of a piece of mine: wait (host) until ready_seq[i] >= s, make
+//               the pushing stream (one per peer on another GPU) wait for ready[i][s % R], copy,
+//               record pushed[j][i][s % R]; j's stream joins its pushing streams and records
+//               done[j][s % R]; publish pushed_seq[j] = s
+//   receive(j)  for every sender i of a piece of mine: wait (host) until pushed_seq[i] >= s, make
+//               j's stream wait for pushed[i][j][s % R]; publish received_seq[j] = s
+//   release(j)  local: the given stream waits for my own done[j][s_last % R] -- what a sender may
+//               overwrite depends on its own copies only, no rank waits for another's progress
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -84,7 +97,9 @@ struct rank_state {
     hipEvent_t fork = nullptr;                 // j's stream -> its per-peer streams
     std::vector<hipStream_t> peer_stream;      // [i]: pulls from rank i (null: pull on j's own stream)
     std::vector<hipEvent_t> peer_done;         // [i]
+    std::vector<hipEvent_t> pushed;            // push form: [i * kRing + slot]: my pieces for rank i have been written
     std::atomic<std::uint64_t> ready_seq{0}, done_seq{0}, released_seq{0};
+    std::atomic<std::uint64_t> pushed_seq{0}, received_seq{0};          // push form
     std::uint64_t seq = 0;                     // exchanges begun; touched by the rank's caller only
     float *scratch = nullptr;                  // all-reduce: P x count floats
     std::size_t scratch_floats = 0;
@@ -96,6 +111,7 @@ struct mggcn_comm {
     std::vector<ncclComm_t> comms;      // rccl transport; empty for p2p
     std::vector<int> devices;
     bool p2p = false;
+    bool push = false;                  // p2p: senders write (MGGCN_P2P_PUSH=1) instead of receivers reading
     unsigned flags = 0;                 // MGGCN_COMM_DEFER_RELEASE | MGGCN_COMM_SKIP_SELF
     std::vector<std::unique_ptr<rank_state>> rk;   // p2p
 };
@@ -139,6 +155,11 @@ void p2p_release_rank(mggcn_comm *c, int j, hipStream_t st) {
     rank_state &me = *c->rk[j];
     const std::uint64_t s = me.seq;
     if (me.released_seq.load(std::memory_order_relaxed) >= s) return;
+    if (c->push) {                                                 // my send buffers depend on my own copies only
+        if (s) CHECK_HIP(hipStreamWaitEvent(st, me.done[s % kRing], 0));
+        me.released_seq.store(s, std::memory_order_release);
+        return;
+    }
     for (int i = 0; i < size_of(c); i++) {
         if (i == j) continue;
         await(c->rk[i]->done_seq, s, "the end", j, i);
@@ -154,11 +175,16 @@ std::uint64_t p2p_begin(mggcn_comm *c, int j, hipStream_t st) {
     if (me.seq - me.released_seq.load(std::memory_order_relaxed) >= (std::uint64_t)kRing / 2) p2p_release_rank(c, j, st);
     const std::uint64_t s = ++me.seq;
     if (s > (std::uint64_t)kRing)                                  // slot s % R was last used by exchange s - R
-        for (int i = 0; i < size_of(c); i++)
-            if (i != j) {
+        for (int i = 0; i < size_of(c); i++) {
+            if (i == j) continue;
+            if (c->push) {
+                await(c->rk[i]->pushed_seq, s - kRing, "the pushes", j, i);         // i has waited for my ready[s - R] ...
+                await(c->rk[i]->received_seq, s - kRing, "the receipt", j, i);      // ... and for my pushed[i][s - R]
+            } else {
                 await(c->rk[i]->done_seq, s - kRing, "the end", j, i);              // i has waited for my ready[s - R] ...
                 await(c->rk[i]->released_seq, s - kRing, "the release", j, i);      // ... and for my done[s - R]
             }
+        }
     CHECK_HIP(hipEventRecord(me.ready[s % kRing], st));
     me.ready_seq.store(s, std::memory_order_release);
     return s;
@@ -199,6 +225,61 @@ void p2p_pull(mggcn_comm *c, int j, std::uint64_t s, hipStream_t st, const std::
         }
     CHECK_HIP(hipEventRecord(me.done[s % kRing], st));
     me.done_seq.store(s, std::memory_order_release);
+}
+
+// push form, rank j's copies of exchange s: my pieces into every receiver's buffer as soon as that buffer is free.
+// all_items[i] = what receiver i gets (the pull form's list); mine are the entries with src == j.
+void p2p_push(mggcn_comm *c, int j, std::uint64_t s, hipStream_t st, const std::vector<std::vector<pull_item>> &all_items) {
+    rank_state &me = *c->rk[j];
+    CHECK_HIP(hipSetDevice(c->devices[j]));
+    for (const auto &it : all_items[j])                            // my own piece: nobody to wait for
+        if (it.src == j && it.count) copy_f32(c, it.dst, j, it.from, j, it.count, st);
+    bool forked = false;
+    std::vector<char> joined(size_of(c), 0);
+    for (int i = 0; i < size_of(c); i++) {
+        if (i == j) continue;
+        bool any = false;
+        hipStream_t ps = me.peer_stream[i];
+        for (const auto &it : all_items[i]) {
+            if (it.src != j || !it.count) continue;
+            if (!any) {
+                await(c->rk[i]->ready_seq, s, "the start", j, i);
+                hipEvent_t free_i = c->rk[i]->ready[s % kRing];   // i's receive buffer is free
+                if (ps) {
+                    if (!forked) { CHECK_HIP(hipEventRecord(me.fork, st)); forked = true; }
+                    CHECK_HIP(hipStreamWaitEvent(ps, me.fork, 0)); // my piece has been produced
+                    CHECK_HIP(hipStreamWaitEvent(ps, free_i, 0));
+                } else {
+                    CHECK_HIP(hipStreamWaitEvent(st, free_i, 0));
+                }
+                any = true;
+            }
+            copy_f32(c, it.dst, i, it.from, j, it.count, ps ? ps : st);
+        }
+        if (!any) continue;
+        CHECK_HIP(hipEventRecord(me.pushed[(size_t)i * kRing + s % kRing], ps ? ps : st));
+        if (ps) joined[i] = 1;
+    }
+    for (int i = 0; i < size_of(c); i++)
+        if (joined[i]) CHECK_HIP(hipStreamWaitEvent(st, me.pushed[(size_t)i * kRing + s % kRing], 0));
+    CHECK_HIP(hipEventRecord(me.done[s % kRing], st));             // my send buffers are mine again after this
+    me.done_seq.store(s, std::memory_order_release);
+    me.pushed_seq.store(s, std::memory_order_release);
+}
+
+// push form: rank j's stream waits for the pieces the others wrote into its buffer
+void p2p_receive(mggcn_comm *c, int j, std::uint64_t s, hipStream_t st, const std::vector<pull_item> &items) {
+    rank_state &me = *c->rk[j];
+    CHECK_HIP(hipSetDevice(c->devices[j]));
+    std::vector<char> from(size_of(c), 0);
+    for (const auto &it : items)
+        if (it.count && it.src != j) from[it.src] = 1;
+    for (int i = 0; i < size_of(c); i++) {
+        if (!from[i]) continue;
+        await(c->rk[i]->pushed_seq, s, "the pushes", j, i);
+        CHECK_HIP(hipStreamWaitEvent(st, c->rk[i]->pushed[(size_t)j * kRing + s % kRing], 0));
+    }
+    me.received_seq.store(s, std::memory_order_release);
 }
 
 void p2p_finish(mggcn_comm *c, int j, hipStream_t st, bool may_defer) {
@@ -288,6 +369,8 @@ MGGCN_API mggcn_comm *mggcn_comm_init_all(int P, const int *devices) {
     // eight ranks x seven extra streams on ONE card doubled the epoch of `mg_gcn -P 8` there (105.9 against 52.1 ms: the runtime
     // multiplexes the streams over four hardware queues; profiles/experiments/cli_p8_variants_r04.log).
     // MGGCN_P2P_PEER_STREAMS=0: never; =1: always, same device or not (tests: the only way to run this path on a one-GPU box).
+    const char *push = std::getenv("MGGCN_P2P_PUSH");
+    c->push = push && std::atoi(push) != 0;
     const char *ps = std::getenv("MGGCN_P2P_PEER_STREAMS");
     const int peer_mode = ps ? std::atoi(ps) : -1;                 // -1: across devices only
     for (int j = 0; j < P; j++) {
@@ -299,6 +382,10 @@ MGGCN_API mggcn_comm *mggcn_comm_init_all(int P, const int *devices) {
             CHECK_HIP(hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming));
         }
         CHECK_HIP(hipEventCreateWithFlags(&r.fork, hipEventDisableTiming));
+        if (c->push) {
+            r.pushed.assign((size_t)P * kRing, nullptr);
+            for (auto &e : r.pushed) CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         r.peer_stream.assign(P, nullptr);
         r.peer_done.assign(P, nullptr);
         int least = 0, greatest = 0;
@@ -322,6 +409,7 @@ MGGCN_API void mggcn_comm_destroy(mggcn_comm *comm) {
         (void)hipEventDestroy(r.fork);
         for (auto &s : r.peer_stream) if (s) (void)hipStreamDestroy(s);
         for (auto &e : r.peer_done) if (e) (void)hipEventDestroy(e);
+        for (auto &e : r.pushed) if (e) (void)hipEventDestroy(e);
         if (r.scratch) (void)hipFree(r.scratch);
     }
     delete comm;
@@ -329,7 +417,7 @@ MGGCN_API void mggcn_comm_destroy(mggcn_comm *comm) {
 
 MGGCN_API int mggcn_comm_size(const mggcn_comm *comm) { return size_of(comm); }
 
-MGGCN_API const char *mggcn_comm_transport(const mggcn_comm *comm) { return comm->p2p ? "p2p" : "rccl"; }
+MGGCN_API const char *mggcn_comm_transport(const mggcn_comm *comm) { return !comm->p2p ? "rccl" : comm->push ? "p2p-push" : "p2p"; }
 
 MGGCN_API void mggcn_comm_set_exchange_flags(mggcn_comm *comm, unsigned flags) { comm->flags = flags; }
 
@@ -354,7 +442,13 @@ void p2p_all_ranks(mggcn_comm *c, const mggcn_stream_t *streams, bool may_defer,
     const int P = size_of(c);
     std::vector<std::uint64_t> s(P);
     for (int j = 0; j < P; j++) s[j] = p2p_begin(c, j, as_stream(streams[j]));
-    for (int j = 0; j < P; j++) p2p_pull(c, j, s[j], as_stream(streams[j]), items(j));
+    if (c->push) {
+        std::vector<std::vector<pull_item>> all(P);
+        for (int j = 0; j < P; j++) all[j] = items(j);
+        for (int j = 0; j < P; j++) p2p_push(c, j, s[j], as_stream(streams[j]), all);
+        for (int j = 0; j < P; j++) p2p_receive(c, j, s[j], as_stream(streams[j]), all[j]);
+    } else
+        for (int j = 0; j < P; j++) p2p_pull(c, j, s[j], as_stream(streams[j]), items(j));
     for (int j = 0; j < P; j++) {
         CHECK_HIP(hipSetDevice(c->devices[j]));
         p2p_finish(c, j, as_stream(streams[j]), may_defer);
@@ -444,9 +538,20 @@ MGGCN_API void mggcn_comm_allreduce_sum_f32(mggcn_comm *comm, float *const *bufs
 
 // ---- one rank's share, from that rank's enqueue thread ----------------------------------------
 namespace {
-void p2p_one_rank(mggcn_comm *c, int j, mggcn_stream_t stream, bool may_defer, const std::vector<pull_item> &items) {
+// peer_state: the lists name memory the RECEIVER allocates before it begins (the all-reduce scratch): read them only
+// after every receiver has begun this exchange
+template <typename Items>
+void p2p_one_rank(mggcn_comm *c, int j, mggcn_stream_t stream, bool may_defer, Items &&items, bool peer_state = false) {
     const std::uint64_t s = p2p_begin(c, j, as_stream(stream));
-    p2p_pull(c, j, s, as_stream(stream), items);
+    if (c->push) {
+        std::vector<std::vector<pull_item>> all(size_of(c));
+        for (int i = 0; i < size_of(c) && peer_state; i++)
+            if (i != j) await(c->rk[i]->ready_seq, s, "the start", j, i);
+        for (int i = 0; i < size_of(c); i++) all[i] = items(i);
+        p2p_push(c, j, s, as_stream(stream), all);
+        p2p_receive(c, j, s, as_stream(stream), all[j]);
+    } else
+        p2p_pull(c, j, s, as_stream(stream), items(j));
     p2p_finish(c, j, as_stream(stream), may_defer);
 }
 }  // namespace
@@ -454,7 +559,7 @@ void p2p_one_rank(mggcn_comm *c, int j, mggcn_stream_t stream, bool may_defer, c
 MGGCN_API void mggcn_comm_broadcast_rank_f32(mggcn_comm *comm, int rank, const float *send_root, float *const *recv,
                                              size_t count, int root, mggcn_stream_t stream) {
     if (comm->p2p) {
-        p2p_one_rank(comm, rank, stream, true, broadcast_items(comm, rank, send_root, recv, count, root));
+        p2p_one_rank(comm, rank, stream, true, [&](int i) { return broadcast_items(comm, i, send_root, recv, count, root); });
         return;
     }
     CHECK_HIP(hipSetDevice(comm->devices[rank]));
@@ -464,7 +569,7 @@ MGGCN_API void mggcn_comm_broadcast_rank_f32(mggcn_comm *comm, int rank, const f
 MGGCN_API void mggcn_comm_allgather_rank_f32(mggcn_comm *comm, int rank, const float *const *send, float *const *recv,
                                              size_t count, mggcn_stream_t stream) {
     if (comm->p2p) {
-        p2p_one_rank(comm, rank, stream, true, allgather_items(comm, rank, send, recv, count));
+        p2p_one_rank(comm, rank, stream, true, [&](int i) { return allgather_items(comm, i, send, recv, count); });
         return;
     }
     CHECK_HIP(hipSetDevice(comm->devices[rank]));
@@ -477,7 +582,7 @@ MGGCN_API void mggcn_comm_alltoallv_rank_f32(mggcn_comm *comm, int rank, const f
     std::vector<size_t> sdis((size_t)P * P, 0), rdis((size_t)P * P, 0);
     mggcn_comm_alltoallv_displacements(P, counts, sdis.data(), rdis.data());
     if (comm->p2p) {
-        p2p_one_rank(comm, rank, stream, true, alltoallv_items(comm, rank, send, recv, counts, sdis, rdis));
+        p2p_one_rank(comm, rank, stream, true, [&](int i) { return alltoallv_items(comm, i, send, recv, counts, sdis, rdis); });
         return;
     }
     CHECK_RCCL(ncclGroupStart());                     // this rank's sends and receives are one operation
@@ -491,7 +596,7 @@ MGGCN_API void mggcn_comm_allreduce_sum_rank_f32(mggcn_comm *comm, int rank, flo
     if (comm->p2p) {
         if (P == 1 || count == 0) return;
         allreduce_scratch(comm, rank, count);
-        p2p_one_rank(comm, rank, stream, false, allreduce_items(comm, rank, bufs, count));
+        p2p_one_rank(comm, rank, stream, false, [&](int i) { return allreduce_items(comm, i, bufs, count); }, true);
         allreduce_sum_local(comm, rank, bufs[rank], count, stream);
         return;
     }

@@ -124,6 +124,6 @@ def test_bench_distributed_path_over_rccl_with_one_rank():
     assert out["loss_first_last"][1] < out["loss_first_last"][0]
     # the CLI legs of the N > 1 line, here with the one rank: RCCL from the rank's enqueue thread, the peer-copy transport,
     # and the reference's one-thread form -- all three at the Python form's first loss
-    for leg, transport, threads in (("cli", "rccl", 1), ("cli_p2p", "p2p", 1), ("cli_serial", "rccl", 0)):
+    for leg, transport, threads in (("cli", "rccl", 1), ("cli_p2p", "p2p", 1), ("cli_serial", "rccl", 0), ("cli_p2p_push", "p2p-push", 1)):
         assert out[f"{leg}_epoch_ms"] > 0 and out[f"{leg}_transport"] == transport and out[f"{leg}_enqueue_threads"] == threads, out
         assert abs(out[f"{leg}_loss_first"] - out["loss_first_last"][0]) <= 1e-4 * out["loss_first_last"][0]

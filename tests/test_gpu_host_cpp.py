@@ -112,6 +112,26 @@ def test_cpp_dist_per_peer_pulling_streams():
     assert "TEST FAILED" not in r.stdout and r.stdout.count("TEST PASSED") >= 12, r.stdout
 
 
+@pytest.mark.parametrize("P,extra", [(2, {}), (4, {}), (4, {"MGGCN_P2P_PEER_STREAMS": "1"}), (8, {})])
+def test_cpp_dist_senders_push(P, extra):
+    """MGGCN_P2P_PUSH=1: the peer-copy transport with the copies turned round -- the SENDER writes its piece into every
+    receiver's buffer once that buffer is free, receivers only wait (csrc/comm.cpp: p2p_push / p2p_receive; a sender's release is
+    local).  Same suite: every schedule at 1e-4 against the single-GPU model, enqueue threads and one thread bit-identical, the
+    late rank still gets the original data; with one pushing stream per peer as between different GPUs, and without."""
+    r = _run([os.path.join(BIN, "test_dist"), str(P)], env=dict({"MGGCN_OVERSUBSCRIBE": "1", "MGGCN_P2P_PUSH": "1"}, **extra))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "TEST FAILED" not in r.stdout and r.stdout.count("TEST PASSED") >= 12, r.stdout
+    assert "transport=p2p-push" in r.stdout
+
+
+def test_cpp_dist_senders_push_wraps_the_event_ring():
+    """the push form with 40 pieces per SpMM: its own event slots (ready / pushed per pair) are re-used every 32 exchanges"""
+    r = _run([os.path.join(BIN, "test_dist"), "4", "1536", "42", "24", "6", "32", "16"],
+             env={"MGGCN_OVERSUBSCRIBE": "1", "MGGCN_DIST_CHUNKS": "40", "MGGCN_P2P_PUSH": "1"})
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "TEST FAILED" not in r.stdout and r.stdout.count("TEST PASSED") >= 12, r.stdout
+
+
 def test_cpp_dist_many_pieces_wrap_the_event_ring():
     """40 pieces per SpMM and ONE release at its end: more exchanges in a row than the peer-copy transport has event slots per
     rank (32) -- slots are re-used, ranks that are 16 exchanges behind with their releases release on the spot
