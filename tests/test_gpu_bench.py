@@ -71,6 +71,22 @@ def test_bench_whose_ranks_fail_still_times_the_product_cli():
 
 
 @pytest.mark.gpu
+def test_bench_whose_ranks_fail_after_the_timed_epochs_keeps_the_headline():
+    """... and ranks that go down in the extras AFTER the timed epochs (test hook) cost only the extras: the headline rank 0 had
+    parked for the launching process is printed, with `extras_error`."""
+    env = dict(os.environ, MGGCN_BENCH_REHEARSAL="1", MGGCN_BENCH_FAIL_RANKS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scale", "0.05"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _one_json_line(r.stdout)
+    assert REQUIRED <= set(out) and out["n_gpus"] == 2 and out["value"] > 0 and out["roofline"]["achieved"] > 0
+    assert "exited with code" in out["extras_error"] and "comm" not in out and "value_source" not in out
+    assert out["loss_first_last"][1] < out["loss_first_last"][0]
+
+
+@pytest.mark.gpu
 def test_bench_multi_rank_rehearsal_prints_one_json_line():
     out = _rehearsal([])
     assert REQUIRED <= set(out)
