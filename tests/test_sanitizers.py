@@ -3,7 +3,11 @@ CPU: `make -C tests/native sanitize` builds tests/native/pl
 runs both.  Under test: the SpMM plan builders' host passes (mg-gcn_amd/csrc/plan_host.cpp -- threaded; the packed entry
 streams are decoded and replayed as an SpMM against the oracle), the host preprocessing (mg-gcn_amd/csrc/host_prep.cpp
 -- threaded; bit-exact against the oracle) and the per-GPU command queues of the single-process host layer
-(mg-gcn_amd/host/enqueue.hpp).  GPU sanitizers do not exist on this pool; the device side is covered by the parity tests."""
+(mg-gcn_amd/host/enqueue.hpp).  Second binary, tests/native/comm_sim_test.cpp: the peer-copy transport of libmggcn_comm.so
+(mg-gcn_amd/csrc/comm.cpp compiled as is) on a MODEL of HIP's stream / event semantics (tests/native/hipsim/): every rank a device
+of its own, queued operations executed in random and adversarial orders, P enqueue threads under ThreadSanitizer, and mutation
+runs that drop event waits (one at a time, one kind at a time) and must be noticed.
+GPU sanitizers do not exist on this pool; the device side is covered by the parity tests."""
 import os
 import subprocess
 
@@ -15,6 +19,8 @@ def test_host_code_is_clean_under_asan_ubsan_and_tsan():
                        timeout=900)
     out = r.stdout + r.stderr
     assert r.returncode == 0, out[-4000:]
-    assert out.count("ALL PASSED") == 2, out[-4000:]                  # once per sanitizer build
+    assert out.count("ALL PASSED") == 4, out[-4000:]                  # two binaries, once per sanitizer build
+    assert out.count("scenarios of the peer-copy transport on the stream model, 0 failed") == 2, out[-4000:]
+    assert "NOT NOTICED" not in out and "DEADLOCK" not in out
     assert "TEST FAILED" not in out and "ERROR: AddressSanitizer" not in out and "WARNING: ThreadSanitizer" not in out
     assert "runtime error" not in out                                # UndefinedBehaviorSanitizer
