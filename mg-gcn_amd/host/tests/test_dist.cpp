@@ -210,7 +210,8 @@ static void test_late_rank(std::size_t P) {
     R.zero(ctx);
     ctx.sync();
     // the delay: ten 3072^3 products on the late rank's comm stream (several ms)
-    const std::uint32_t g = 3072;
+    // (MGGCN_TEST_DELAY_GEMM: a smaller product for the model runs of tests/native, where a "device" is a CPU loop)
+    const std::uint32_t g = std::getenv("MGGCN_TEST_DELAY_GEMM") ? (std::uint32_t)std::atoi(std::getenv("MGGCN_TEST_DELAY_GEMM")) : 3072;
     ctx[late].set();
     dn_matrix<r_t> ga(g, g), gb(g, g), gc(g, g);
     ga.zero(ctx[late]); gb.zero(ctx[late]);
@@ -235,7 +236,8 @@ static void test_late_rank(std::size_t P) {
     const std::vector<float> want(vals.begin(), vals.begin() + (rows / P) * d);
     for (std::size_t j = 0; j < P; j++) { ctx[j].set(); CHECK(R[j].to_host() == want); }
     // the timing claim needs the on-time rank's streams on hardware queues of their own: on ONE device that holds up to four ranks
-    const bool timed = ctx.transport() == "p2p" && P <= 4;
+    // (delay == 0: the stream model of tests/native has no clock -- the data claims above still hold there)
+    const bool timed = ctx.transport() == "p2p" && P <= 4 && delay > 0.f;
     if (timed) CHECK(t_on_time < 0.5f * delay);
     std::printf("%s: late rank: delay %.2f ms, on-time receiver's exchange %.3f ms%s, transport %s, threads %d\n",
                 (!timed || t_on_time < 0.5f * delay) ? "TEST PASSED" : "TEST FAILED", delay, t_on_time, timed ? "" : " (not asserted)",

@@ -133,6 +133,7 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
         const int cls = from->device != s->device ? HIPSIM_CROSS_DEVICE
                       : (s->user && !from->user)  ? HIPSIM_JOIN
                       : (!s->user && from->user)  ? HIPSIM_FORK
+                      : (s != from && s->user)    ? HIPSIM_USER_EDGE
                                                   : HIPSIM_NO_CLASS;
         dropped = dropped || cls == g_drop_class;
     }

@@ -15,7 +15,8 @@ void hipsim_drop_wait(std::int64_t k);                                 // mutati
 //   CROSS_DEVICE  the event was recorded on a stream of another device (another rank's progress: ready / done / pushed)
 //   JOIN          a test-made stream waits for a stream the code under test created on the same device (its copies have landed)
 //   FORK          such a stream waits for the test-made stream of its device (the buffer it is about to touch is free / produced)
-enum { HIPSIM_NO_CLASS = 0, HIPSIM_CROSS_DEVICE = 1, HIPSIM_JOIN = 2, HIPSIM_FORK = 3 };
+//   USER_EDGE     a test-made stream waits for ANOTHER test-made stream of the same device (the host layer's compute <-> comm edges)
+enum { HIPSIM_NO_CLASS = 0, HIPSIM_CROSS_DEVICE = 1, HIPSIM_JOIN = 2, HIPSIM_FORK = 3, HIPSIM_USER_EDGE = 4 };
 void hipsim_drop_class(int cls);
 std::uint64_t hipsim_ops_executed();
 void hipsim_reset();                                                   // forget every stream / event / counter (between scenarios)
