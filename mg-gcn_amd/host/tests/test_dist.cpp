@@ -229,6 +229,9 @@ static void test_late_rank(std::size_t P) {
     ctx.record("t1", cs);
     ctx.register_timer("exchange", "t0", "t1");
     ctx.on(late, [c = ctx[late]] { c.register_timer("delay", "delay-0", "delay-1"); });
+    // the overwrite below runs on the COMPUTE stream: ordered after the exchange on every transport (a collective frees its send
+    // buffer in the order of the stream it was issued on -- found missing by the stream model of tests/native on the RCCL transport)
+    ctx.wait("t1", 0);
     ctx.release_sends(0);                                  // the root's compute stream waits for every reader ...
     B.zero(ctx);                                           // ... and only then overwrites what it sent
     ctx.sync();

@@ -1,6 +1,6 @@
 #!/bin/bash
 BIN=/root/repo/tests/native/_build/host_dist_sim_asan
-export MGGCN_COMM_TRANSPORT=p2p MGGCN_TEST_DELAY_GEMM=48 ASAN_OPTIONS=detect_leaks=0
+export MGGCN_TEST_DELAY_GEMM=48 MGGCN_COMM_TRANSPORT=${SWEEP_TRANSPORT:-p2p} ASAN_OPTIONS=detect_leaks=0
 run() {
   P=$1 pol=$2 seed=$3 push=$4 chunks=$5
   out=$(HIPSIM_POLICY=$pol HIPSIM_SEED=$seed MGGCN_P2P_PUSH=$push MGGCN_DIST_CHUNKS=$chunks timeout 300 $BIN $P 2>&1); rc=$?

@@ -7,7 +7,9 @@
 // Here every rank is its own "device", nothing runs when it is enqueued, and a drain executes the queued operations in a
 // random or adversarial order that respects nothing but stream order and the event waits the transport asked for.
 //
-// Each scenario: P ranks x {receivers pull, senders push} x {P enqueue threads + per-rank entry points, one thread + all-ranks
+// The RCCL transport runs too, on a model of RCCL's contract (hipsim/rccl/rccl.h): its multi-rank branches -- grouped calls from one
+// thread, per-rank calls from P threads, the send / receive all-to-all -- have never met more than one real rank either.
+// Each scenario: P ranks x {receivers pull, senders push, RCCL} x {P enqueue threads + per-rank entry points, one thread + all-ranks
 // entry points} x exchange flags, several iterations of all-gather / broadcast / all-to-all / all-reduce.  Around every
 // exchange a rank FILLS what it sends (a kernel on its stream, values that name rank / iteration / position), CHECKS every
 // word it received (a kernel after the exchange) and POISONS what it sent as soon as the transport's contract lets it
@@ -61,6 +63,7 @@ struct scenario {
     int value_period;           // fills depend on iteration / value_period: > 1 when several iterations pass between two releases
                                 // (a sender that has not released may only "overwrite" what it sent with the same values)
     int P;
+    bool rccl;                  // the RCCL transport (on the model of rccl/rccl.h) instead of peer copies
     bool push, threaded;
     unsigned flags;
     int release_every;          // with MGGCN_COMM_DEFER_RELEASE: explicit release after every n-th exchange (poison only then)
@@ -202,7 +205,7 @@ static long run(const scenario &sc, std::int64_t drop_wait = -1, std::uint64_t *
     hipsim_set_schedule(sc.seed, sc.policy);
     hipsim_drop_wait(drop_wait);
     hipsim_drop_class(drop_class);
-    setenv("MGGCN_COMM_TRANSPORT", "p2p", 1);
+    setenv("MGGCN_COMM_TRANSPORT", sc.rccl ? "rccl" : "p2p", 1);
     setenv("MGGCN_P2P_PUSH", sc.push ? "1" : "0", 1);
     if (sc.peer_streams < 0) unsetenv("MGGCN_P2P_PEER_STREAMS");
     else setenv("MGGCN_P2P_PEER_STREAMS", sc.peer_streams ? "1" : "0", 1);
@@ -251,11 +254,13 @@ int main() {
     int failures = 0, scenarios = 0;
     const unsigned product = MGGCN_COMM_DEFER_RELEASE | MGGCN_COMM_SKIP_SELF;     // what host/dist_matrix.hpp sets
     for (const int P : {2, 3, 4, 8})
-        for (const bool push : {false, true})
+        for (const int transport : {0, 1, 2})                                       // receivers pull, senders push, RCCL
             for (const bool threaded : {true, false})
                 for (const int variant : {0, 1, 2, 3}) {
+                    if (transport == 2 && variant == 3) continue;                   // (no copying streams to vary)
                     scenario sc{};
-                    sc.P = P; sc.push = push; sc.threaded = threaded;
+                    const bool push = transport == 1;
+                    sc.P = P; sc.push = push; sc.rccl = transport == 2; sc.threaded = threaded;
                     sc.flags = variant == 1 ? 0u : product;                         // 1: NCCL's contract, nothing deferred
                     sc.release_every = variant == 2 ? 32 : 1;                        // 2: releases are rare -> the forced release, ring re-use
                     sc.value_period = variant == 2 ? 8 : 1;                          //    (8 iterations x 4 exchanges between two releases)
@@ -269,12 +274,12 @@ int main() {
                         if (bad) {
                             failures++;
                             std::printf("TEST FAILED: P=%d %s %s flags=%u release_every=%d peer_streams=%d policy=%d: %ld bad\n", P,
-                                        push ? "push" : "pull", threaded ? "threads" : "one thread", sc.flags, sc.release_every,
+                                        sc.rccl ? "rccl" : push ? "push" : "pull", threaded ? "threads" : "one thread", sc.flags, sc.release_every,
                                         sc.peer_streams, (int)sc.policy, bad);
                         }
                     }
                 }
-    std::printf("%s: %d scenarios of the peer-copy transport on the stream model, %d failed\n", failures ? "TEST FAILED" : "TEST PASSED",
+    std::printf("%s: %d scenarios of the two transports on the stream model, %d failed\n", failures ? "TEST FAILED" : "TEST PASSED",
                 scenarios, failures);
 
     // can the model tell?  one thread (deterministic call order), one dropped hipStreamWaitEvent at a time

@@ -1,8 +1,13 @@
-// tests/native/hipsim/rccl/rccl.h -- NOT RCCL: declarations that let mg-gcn_amd/csrc/comm.cpp compile on the CPU for the model
-// runs of its PEER-COPY transport (tests/native/comm_sim_test.cpp).  Every function aborts: the RCCL transport has no model here.
+// tests/native/hipsim/rccl/rccl.h -- NOT RCCL: a MODEL of the part of its contract that mg-gcn_amd/csrc/comm.cpp relies on, on the
+// streams of hip/hip_runtime.h (hipsim.cpp).  A call -- or everything between ncclGroupStart and ncclGroupEnd on one communicator --
+// is ONE operation on the stream it was given; it runs when the matching operation of every rank it involves (all of them for a
+// collective, the other side for a send / receive, matched by call order) has reached the head of ITS stream, and all of them
+// run as one step: ranks that issue their collectives in different orders, or leave one out, hang -- reported as a deadlock.
+// Counts and roots must agree; sums are formed in rank order.  fp32 only, one process, communicators from ncclCommInitAll.
 #pragma once
 #include <cstddef>
 #include <hip/hip_runtime.h>
+struct hipsim_nccl_comm;
 typedef struct hipsim_nccl_comm *ncclComm_t;
 typedef int ncclResult_t;
 enum : int { ncclSuccess = 0 };
