@@ -16,6 +16,9 @@ GPU sanitizers do not exist on this pool; the device side is covered by the pari
 import os
 import subprocess
 
+import numpy as np
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -30,3 +33,35 @@ def test_host_code_is_clean_under_asan_ubsan_and_tsan():
     assert "NOT NOTICED" not in out and "DEADLOCK" not in out
     assert "TEST FAILED" not in out and "ERROR: AddressSanitizer" not in out and "WARNING: ThreadSanitizer" not in out
     assert "runtime error" not in out                                # UndefinedBehaviorSanitizer
+
+
+@pytest.mark.parametrize("transport,mode,threads", [("p2p", "allgather", "1"), ("rccl", "rounds", "1"), ("rccl", "halo", "0")])
+def test_cli_on_the_stream_model_matches_the_dist_oracle(pkg, oracle, tmp_path, transport, mode, threads):
+    """`mg_gcn -P 4 -R 1 -E 2 train ...` -- host/main.cpp and the whole C++ host layer compiled as is over the CPU model of the C ABI
+    (tests/native/abisim.cpp), four ranks on devices of their own, peer copies or the modelled RCCL, one enqueue thread per rank
+    (ThreadSanitizer build) or the reference's single thread: the epoch-0 loss and accuracy equal oracle.DistGcn's at 1e-4 (classes
+    padded to a multiple of P, src/main.cpp:135).  The host layer's LOGIC end to end without a GPU; the HIP kernels are the GPU
+    suite's business."""
+    exe = os.path.join(ROOT, "tests", "native", "_build", "mg_gcn_sim_tsan")
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "native"), exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    n, F, C, P = 1536, 24, 6, 4
+    ip, ix, dv = pkg.datasets.synth_powerlaw_csr(n, n * 20, 900, seed=17)
+    rng = np.random.default_rng(18)
+    X = rng.standard_normal((n, F), dtype=np.float32)
+    Y = rng.integers(0, C, size=(n, 1)).astype(np.int32)
+    Y[0, 0] = C - 1
+    d = tmp_path / "permuted" / "synth"
+    pkg.datasets.write_dataset(str(d), ip, ix, dv, X, Y)
+    env = dict(os.environ, MGGCN_COMM_TRANSPORT=transport, MGGCN_DIST_MODE=mode, MGGCN_ENQUEUE_THREADS=threads, HIPSIM_POLICY="0",
+               HIPSIM_SEED="9", TSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe, "-P", str(P), "-R", "1", "-E", "2", "train", str(d), "2", "16", "16"], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    lines = r.stderr.strip().splitlines()
+    got = [tuple(float(x) for x in ln.split()) for ln in lines if len(ln.split()) == 4 and ln.split()[0].isdigit()]
+    assert [int(g[0]) for g in got] == [0, 1]
+    O = oracle.DistGcn(oracle.Csr(ip, ix, dv, n), [F, 16, 16, C], P)
+    want = O.train_forward(X, Y)
+    assert abs(got[0][1] - want[0]) <= 1e-4 * want[0] and abs(got[0][2] - want[1]) <= 3.0 / n, (got, want)
+    assert got[1][1] < got[0][1]                                      # and it trains
