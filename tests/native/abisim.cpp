@@ -30,6 +30,9 @@ void setup() {
         const char *p = std::getenv("HIPSIM_POLICY"), *s = std::getenv("HIPSIM_SEED");
         hipsim_set_schedule(s ? std::strtoull(s, nullptr, 10) : 1, (hipsim_policy)(p ? std::atoi(p) : 0));
         if (const char *c = std::getenv("HIPSIM_DROP_CLASS")) hipsim_drop_class(std::atoi(c));     // mutation runs: one kind of wait ignored
+        if (std::getenv("HIPSIM_STATS"))                                                           // operations the run enqueued (a proxy for API calls)
+            std::atexit([] { std::fprintf(stderr, "[hipsim] operations executed %llu, of them event waits asked for %llu\n",
+                                          (unsigned long long)hipsim_ops_executed(), (unsigned long long)hipsim_waits_seen()); });
     });
 }
 hipStream_t st(mggcn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
