@@ -167,6 +167,7 @@ def run_cli_multi_gpu(dataset_dir, P, hidden, mode, overlap, rehearsal, epochs=8
       push     same, the SENDER copies (MGGCN_P2P_PUSH=1: writes over xGMI instead of reads)           -> cli_p2p_push_*
       serial   the reference's process model: ONE host thread issues every GPU's work, RCCL    -> cli_serial_*
       (N > 2)  peer copies pulled on one stream per rank instead of one per xGMI link              -> cli_p2p_one_stream_*
+               peer copies, two pieces per SpMM instead of four (half the host calls)              -> cli_p2p_two_pieces_*
     Each leg is bounded (own session, killed on timeout); a failed leg reports its error and the next one still runs."""
     import tempfile
     cwd = tempfile.mkdtemp(prefix="mggcn_bench_cli_")
@@ -181,6 +182,9 @@ def run_cli_multi_gpu(dataset_dir, P, hidden, mode, overlap, rehearsal, epochs=8
         legs.append(("cli_p2p_push", dict(threads, MGGCN_COMM_TRANSPORT="p2p", MGGCN_P2P_PUSH="1")))
     if not rehearsal and P > 2:          # ... and the peer copies pulled on ONE stream per rank, copy after copy (are the per-peer streams worth it?)
         legs.append(("cli_p2p_one_stream", dict(threads, MGGCN_COMM_TRANSPORT="p2p", MGGCN_P2P_PEER_STREAMS="0")))
+        # ... and in two pieces per SpMM instead of four: the per-peer form issues ~1500 HIP calls per rank and epoch at P = 8 (counted on
+        # the stream model of tests/native) -- is it the host that bounds it?
+        legs.append(("cli_p2p_two_pieces", dict(threads, MGGCN_COMM_TRANSPORT="p2p", MGGCN_DIST_CHUNKS="2")))
     out = {}
     try:
         for key, extra in legs:
